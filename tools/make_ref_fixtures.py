@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Copy the hot-path DATA fixtures of the reference's own tests into tests/golden/ref_fixtures.
+
+Runs in the dev container only (needs /root/reference).  The inputs are the
+uuencoded data files next to the reference's tests (libarchive/test, cat/test,
+tar/test); they are decoded to their binary form and written with a manifest.
+Expected digests of the decoded payloads are the ones measured with the real
+reference -- they are what the oracle must reproduce.
+"""
+import binascii, hashlib, json, os, sys
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "ref_fixtures")
+
+TAR7168 = "7565705704f8f736e966783ba96277df8a37a921031a97d5a63a479d5baf1f49"
+TARBIG = "b4df03c461fe9431ad097be2b6704ea993da915691cd8ecf7d7fee87ca8d595f"
+EXTRACT = "7ae874a578425c31eda93582de9d10b413e18ab7378023a7bde6b82b1c37dff0"
+
+FIXTURES = [
+    # (path under reference, codec, expected decoded size, expected sha256, what the reference test asserts)
+    ("libarchive/test/test_compat_lz4_1.tar.lz4.uu", "lz4", 7168, TAR7168, "test_compat_lz4.c:41-117, two concatenated frames"),
+    ("libarchive/test/test_compat_lz4_2.tar.lz4.uu", "lz4", 7168, TAR7168, "trailing garbage ignored"),
+    ("libarchive/test/test_compat_lz4_3.tar.lz4.uu", "lz4", 7168, TAR7168, "legacy frame"),
+] + [
+    ("libarchive/test/test_compat_lz4_%s.tar.lz4.uu" % v, "lz4", 4233728, TARBIG, "block size / dependence / block checksum variant " + v)
+    for v in ("B4", "B4BD", "B4BDBX", "B5", "B5BD", "B6", "B6BD", "B7", "B7BD")
+] + [
+    ("libarchive/test/test_compat_gzip_1.tgz.uu", "gzip", 7168, TAR7168, "test_compat_gzip.c:40-94, 8 members with FNAME"),
+    ("libarchive/test/test_compat_gzip_2.tgz.uu", "gzip", 7168, TAR7168, "member + trailing junk"),
+    ("libarchive/test/test_read_format_raw.data.gz.uu", "gzip", 4, "b5bb9d8014a0f9b1d61e21e796d78dccdf1352f23cd32812f4850b878ae4944c", "test_read_format_raw.c:122-148 name/mtime"),
+    ("cat/test/test_expand.lz4.uu", "lz4", 29, "7ff3b75ab8f584b2b9198073d0932d03dfabcdb870b21d549fdf701dff9f88d1", "cat/test/test_expand_lz4.c:10-24"),
+    ("cat/test/test_expand.gz.uu", "gzip", 28, "4ac0924acf33ed4aad8411b62a0b0bd5a7ac8e16b46bd23a3ac8eaef04c997a0", "cat/test/test_expand_gz.c:10-24"),
+    ("cat/test/test_empty.lz4.uu", "lz4", 0, hashlib.sha256(b"").hexdigest(), "cat/test/test_empty_lz4.c:9-23"),
+    ("cat/test/test_empty.gz.uu", "gzip", 0, hashlib.sha256(b"").hexdigest(), "cat/test/test_empty_gz.c"),
+    ("tar/test/test_extract.tar.lz4.uu", "lz4", 3072, EXTRACT, "tar/test/test_extract_tar_lz4.c"),
+    ("tar/test/test_extract.tar.gz.uu", "gzip", 3072, EXTRACT, "tar/test/test_extract_tar_gz.c"),
+]
+
+
+def uudecode(text):
+    out = bytearray()
+    started = False
+    for line in text.splitlines():
+        if not started:
+            if line.startswith("begin "):
+                started = True
+            continue
+        if line.strip() == "end":
+            break
+        if not line:
+            continue
+        try:
+            out += binascii.a2b_uu(line)
+        except binascii.Error:
+            nbytes = (((ord(line[0]) - 32) & 63) * 4 + 5) // 3
+            out += binascii.a2b_uu(line[:nbytes])
+    return bytes(out)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    manifest = []
+    for rel, codec, size, sha, note in FIXTURES:
+        raw = uudecode(open(os.path.join(REF, rel), "r", errors="replace").read())
+        name = os.path.basename(rel)[:-3]
+        open(os.path.join(OUT, name), "wb").write(raw)
+        manifest.append({"file": name, "source": rel, "codec": codec, "decoded_size": size,
+                         "decoded_sha256": sha, "pins": note, "stream_sha256": hashlib.sha256(raw).hexdigest()})
+        print(name, len(raw))
+    json.dump(manifest, open(os.path.join(OUT, "manifest.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    sys.exit(main())
