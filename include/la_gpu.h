@@ -1,0 +1,213 @@
+/*
+ * la_gpu.h -- C ABI of the MI355X (gfx950) data plane behind libarchive's
+ * lz4 / gzip read filters.
+ *
+ * This is the `extern "C"` shim the host filters (include/la_filter.h,
+ * libarchive_amd/host/) call from inside their vtable read() -- the ONLY place
+ * a device boundary is crossed.  Plain pointers and sizes,
+ * no C++ or framework types.  Each entry point cites the reference code whose
+ * arithmetic it replaces (paths relative to the reference tree).
+ *
+ * Conventions
+ *   - Functions return LA_OK (0) or a negative la_rc.  Nothing throws.
+ *   - Pointers named d_* are DEVICE pointers; h_* are host pointers.
+ *   - Work is enqueued on the context's HIP stream; results are valid after
+ *     la_gpu_sync() (or after the caller synchronises that stream itself).
+ *   - A context is owned by one host thread (one `struct archive` = one
+ *     thread, reference README.md:194-221); any number of contexts may exist.
+ */
+#ifndef LA_GPU_H
+#define LA_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LA_GPU_ABI_VERSION 1
+
+typedef enum la_rc {
+	LA_OK            = 0,
+	LA_ERR_NO_DEVICE = -1,	/* no usable gfx950 device / HIP runtime failure at open */
+	LA_ERR_HIP       = -2,	/* a HIP call failed; see la_gpu_last_error() */
+	LA_ERR_ARG       = -3,
+	LA_ERR_NOMEM     = -4
+} la_rc;
+
+typedef struct la_gpu_ctx la_gpu_ctx;
+
+/* ---- context ---- */
+int         la_gpu_abi_version(void);
+int         la_gpu_device_count(void);
+/* Opens device `device`, creates a private stream and a small workspace. */
+int         la_gpu_open(int device, la_gpu_ctx **out);
+void        la_gpu_close(la_gpu_ctx *ctx);
+/* Run on a caller-owned hipStream_t instead of the private one (NULL = back to private). */
+int         la_gpu_set_stream(la_gpu_ctx *ctx, void *hip_stream);
+int         la_gpu_sync(la_gpu_ctx *ctx);
+const char *la_gpu_last_error(const la_gpu_ctx *ctx);
+/* Pre-size the context's device workspace (sequence tables, scan scratch) so that
+ * no allocation happens inside a decode call.  Optional. */
+int         la_gpu_reserve(la_gpu_ctx *ctx, uint64_t workspace_bytes);
+
+/* Raw device memory helpers for C hosts that do not own an allocator. */
+int         la_gpu_malloc(la_gpu_ctx *ctx, void **d_ptr, uint64_t bytes);
+int         la_gpu_free(la_gpu_ctx *ctx, void *d_ptr);
+int         la_gpu_malloc_host(la_gpu_ctx *ctx, void **h_ptr, uint64_t bytes);	/* pinned */
+int         la_gpu_free_host(la_gpu_ctx *ctx, void *h_ptr);
+int         la_gpu_memcpy_h2d(la_gpu_ctx *ctx, void *d_dst, const void *h_src, uint64_t bytes);
+int         la_gpu_memcpy_d2h(la_gpu_ctx *ctx, void *h_dst, const void *d_src, uint64_t bytes);
+
+/* Stream-ordered timer (HIP events on the context's stream). */
+int         la_gpu_timer_start(la_gpu_ctx *ctx);
+int         la_gpu_timer_stop(la_gpu_ctx *ctx, float *elapsed_ms);	/* synchronises */
+
+/* ---- per-unit status words written by the device ---- */
+enum {
+	LA_ST_OK                  = 0,
+	LA_ST_LZ4_BAD_BLOCK_SUM   = 1,	/* lz4.c:517-526  -> "malformed lz4 data" */
+	LA_ST_LZ4_DECODE          = 2,	/* lz4.c:594-598  -> "lz4 decompression failed" */
+	LA_ST_LZ4_BAD_HEADER_SUM  = 3,	/* lz4.c:446-451  -> "malformed lz4 data" */
+	LA_ST_LZ4_BAD_CONTENT_SUM = 4,	/* lz4.c:655-660  -> "lz4 stream checksum error" */
+	LA_ST_GZ_DATA             = 5,	/* gzip.c:494-499 -> "gzip decompression failed" */
+	LA_ST_GZ_TRUNCATED        = 6,	/* gzip.c:464-469 -> "truncated gzip input" */
+	LA_ST_GZ_BAD_CRC          = 7,	/* NEW (reference never checks, gzip.c:423) */
+	LA_ST_GZ_BAD_ISIZE        = 8	/* NEW */
+};
+
+/* =====================================================================
+ * XXH32 -- replaces __archive_xxhash.XXH32 (libarchive/xxhash.c:234-319) for
+ * MANY independent hashes at once (one hash is a serial chain).
+ * ===================================================================== */
+typedef struct la_hash_job {
+	uint64_t off;	/* byte offset of the range inside d_base */
+	uint32_t len;
+	uint32_t seed;
+} la_hash_job;
+
+int la_gpu_xxh32_many(la_gpu_ctx *ctx, const uint8_t *d_base,
+    const la_hash_job *d_jobs, uint32_t n_jobs, uint32_t *d_out);
+
+/* =====================================================================
+ * CRC32 -- replaces crc32() (libarchive/archive_crc32.h:43-84, zlib-compatible)
+ * for many ranges; each range is reduced wave-parallel with GF(2) combines.
+ * `seed` of a job is the running crc to continue from (0 for a fresh one).
+ * ===================================================================== */
+int la_gpu_crc32_many(la_gpu_ctx *ctx, const uint8_t *d_base,
+    const la_hash_job *d_jobs, uint32_t n_jobs, uint32_t *d_out);
+
+/* =====================================================================
+ * LZ4 -- replaces the data plane of lz4_filter_read_data_block /
+ * lz4_filter_read_default_stream / _legacy_stream
+ * (libarchive/archive_read_support_filter_lz4.c:471-613, :615-668, :670-721):
+ * block checksum XXH32, LZ4_decompress_safe[_usingDict], content checksum,
+ * header check byte -- for a whole batch of blocks/frames per call.
+ * The host walks the size words (cheap pointer chase) and fills these tables.
+ * ===================================================================== */
+#define LA_LZ4B_STORED    1u	/* size word had bit 31: payload is the data (lz4.c:500-504, :530-552) */
+#define LA_LZ4B_CHECKSUM  2u	/* block_sum holds the LE32 that followed the payload (lz4.c:517-526) */
+#define LA_LZ4B_DEPENDENT 4u	/* frame without the independence bit: matches may reach the previous block (lz4.c:562-591) */
+#define LA_LZ4B_FIRST     8u	/* first block of its frame: dictionary is 64 KiB of zeros (lz4.c:260-261) */
+
+typedef struct la_lz4_block {
+	uint64_t src_off;	/* first payload byte inside d_src (after the 4-byte size word) */
+	uint32_t src_len;	/* payload bytes (size word & 0x7fffffff) */
+	uint32_t dst_cap;	/* frame's block maximum size, or 8 MiB for legacy blocks */
+	uint32_t flags;		/* LA_LZ4B_* */
+	uint32_t block_sum;	/* expected XXH32 of the payload when LA_LZ4B_CHECKSUM */
+} la_lz4_block;
+
+#define LA_LZ4F_CONTENT_SUM 1u	/* content_sum holds the LE32 after the EndMark (lz4.c:639-662) */
+#define LA_LZ4F_HEADER_SUM  2u	/* verify descriptor check byte (lz4.c:446-451) */
+
+typedef struct la_lz4_frame {
+	uint64_t desc_off;	/* offset of FLG inside d_src */
+	uint32_t desc_len;	/* descriptor bytes INCLUDING the trailing check byte (3..15) */
+	uint32_t first_block;	/* index of the frame's first block in the block table */
+	uint32_t n_blocks;
+	uint32_t flags;		/* LA_LZ4F_* */
+	uint32_t content_sum;	/* expected XXH32 of the frame's decoded bytes */
+	uint32_t reserved;
+} la_lz4_frame;
+
+/* Batch summary reduced on the device (first failing event in STREAM order). */
+typedef struct la_batch_summary {
+	uint64_t total_out;		/* decoded bytes of the whole batch */
+	uint32_t n_bad_units;		/* blocks / members with status != 0 */
+	uint32_t n_bad_frames;
+	uint32_t first_bad_unit;	/* 0xFFFFFFFF if none */
+	uint32_t first_bad_frame;	/* 0xFFFFFFFF if none */
+	uint32_t first_zero_unit;	/* first unit that decoded to 0 bytes (ends the stream, SURVEY F11 i); 0xFFFFFFFF if none */
+	uint32_t reserved;
+} la_batch_summary;
+
+#define LA_LZ4_OPT_GENERAL_ONLY 1u	/* force the general (any block size / dependent) expand kernel */
+#define LA_LZ4_OPT_NO_VERIFY    2u	/* skip the three XXH32 checks (the reference's `!stream-checksum` shape) */
+
+typedef struct la_lz4_batch {
+	const uint8_t      *d_src;	/* compressed image (or batch window) in HBM */
+	uint64_t            src_bytes;
+	const la_lz4_block *d_blocks;
+	uint32_t            n_blocks;
+	const la_lz4_frame *d_frames;	/* may be NULL when n_frames == 0 */
+	uint32_t            n_frames;
+	uint8_t            *d_dst;	/* decoded slab: blocks are packed back to back in table order */
+	uint64_t            dst_cap;
+	/* outputs */
+	uint32_t           *d_out_len;		/* [n_blocks]  decoded bytes per block */
+	uint64_t           *d_dst_off;		/* [n_blocks+1] exclusive prefix sums of d_out_len */
+	uint32_t           *d_block_status;	/* [n_blocks]  LA_ST_* */
+	uint32_t           *d_frame_status;	/* [n_frames]  LA_ST_* */
+	la_batch_summary   *d_summary;		/* one record */
+	uint32_t            options;		/* LA_LZ4_OPT_* */
+	uint32_t            reserved;
+} la_lz4_batch;
+
+/* Workspace bytes la_gpu_lz4_decode() needs for this shape (for la_gpu_reserve). */
+uint64_t la_gpu_lz4_workspace_bytes(uint32_t n_blocks, uint64_t src_bytes);
+
+int la_gpu_lz4_decode(la_gpu_ctx *ctx, const la_lz4_batch *batch);
+
+/* =====================================================================
+ * gzip / DEFLATE -- replaces the inflate() loop of gzip_filter_read
+ * (libarchive/archive_read_support_filter_gzip.c:431-511; zlib inflate with
+ * windowBits -15) for a batch of independent members, plus the trailer
+ * CRC32/ISIZE check the reference leaves as a TODO (gzip.c:423).
+ * ===================================================================== */
+typedef struct la_gz_member {
+	uint64_t src_off;	/* first byte of the raw deflate body inside d_src */
+	uint32_t src_len;	/* bytes available for body + trailer (up to the next member / end) */
+	uint32_t dst_cap;	/* capacity reserved for this member's output */
+	uint64_t dst_off;	/* where its output goes inside d_dst */
+} la_gz_member;
+
+typedef struct la_gz_result {
+	uint32_t status;	/* LA_ST_* (a CRC/ISIZE mismatch is reported here but the bytes are still delivered) */
+	uint32_t out_len;	/* bytes produced (also on error: what zlib would have emitted) */
+	uint32_t consumed;	/* deflate body bytes consumed (trailer follows) */
+	uint32_t crc32;		/* CRC32 of the produced bytes */
+} la_gz_result;
+
+typedef struct la_gz_batch {
+	const uint8_t      *d_src;
+	uint64_t            src_bytes;
+	const la_gz_member *d_members;
+	uint32_t            n_members;
+	uint8_t            *d_dst;
+	uint64_t            dst_cap;
+	la_gz_result       *d_results;	/* [n_members] */
+	la_batch_summary   *d_summary;
+	uint32_t            options;
+	uint32_t            reserved;
+} la_gz_batch;
+
+#define LA_GZ_OPT_NO_VERIFY 1u	/* do not compare the trailer (reference behaviour) */
+
+int la_gpu_gzip_decode(la_gpu_ctx *ctx, const la_gz_batch *batch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LA_GPU_H */

@@ -1,0 +1,62 @@
+/*
+ * la_host.h -- host-side (plain C) helpers of the GPU read filters: the frame /
+ * member walkers that turn a compressed image into the job tables of
+ * include/la_gpu.h, and the mapping from device status words back to the
+ * reference's return codes and error strings.
+ *
+ * The walkers restate ONLY the framing of the reference filters (the cheap,
+ * sequential pointer chase); every checksum and every decoded byte is produced
+ * on the device.
+ *   lz4 : libarchive/archive_read_support_filter_lz4.c:289-368 (frame select),
+ *         :370-469 (descriptor), :471-613 (block header), :670-721 (legacy)
+ *   gzip: libarchive/archive_read_support_filter_gzip.c:128-239 (header),
+ *         :398-429 (trailer), :431-511 (member loop)
+ */
+#ifndef LA_HOST_H
+#define LA_HOST_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "la_gpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* How the walked region ends (what the reference does AFTER the last indexed unit) */
+enum {
+	LA_END_EOF = 0,		/* end of input, unrecognised trailing data, or another silent end: rc 0 */
+	LA_END_TRUNCATED,	/* "truncated lz4 input" / "truncated gzip input" */
+	LA_END_MALFORMED,	/* "malformed lz4 data" (descriptor / block size word) */
+	LA_END_MALFORMED_SKIP,	/* "Malformed lz4 data" (skippable frame without a length, lz4.c:349-353) */
+	LA_END_EMPTY_FRAME,	/* a frame without blocks: its checksum is verified, then the stream ends (SURVEY F11 i) */
+	LA_END_NEED_MORE,	/* window ended inside an item and more input may follow (at_eof == 0) */
+	LA_END_GZ_NO_TRAILER	/* deflate body complete, trailer short: ARCHIVE_FATAL without message (gzip.c:419-421) */
+};
+
+typedef struct la_lz4_index {
+	la_lz4_block *blocks;
+	uint32_t      n_blocks, cap_blocks;
+	la_lz4_frame *frames;
+	uint32_t      n_frames, cap_frames;
+	int           end_kind;		/* LA_END_* */
+	uint64_t      consumed;		/* bytes of the image covered by complete items */
+	uint64_t      max_out;		/* sum of dst_cap over blocks (upper bound of decoded bytes) */
+} la_lz4_index;
+
+/* Walk img[0..len).  at_eof: no more input follows this window.  Returns 0, or
+ * -1 on allocation failure.  The index owns its arrays (la_lz4_index_free). */
+int  la_lz4_index_build(const uint8_t *img, uint64_t len, int at_eof, la_lz4_index *idx);
+void la_lz4_index_free(la_lz4_index *idx);
+
+/* Bid functions (lz4.c:138-183, gzip.c:244-255) over a peeked buffer */
+int  la_lz4_bid_bytes(const uint8_t *p, size_t avail);
+
+/* The reference's error string for a device status word / an end kind */
+const char *la_status_message(uint32_t la_st);
+const char *la_end_message(int end_kind, int is_gzip);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

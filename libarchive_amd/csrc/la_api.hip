@@ -1,0 +1,253 @@
+/*
+ * la_api.hip -- the extern "C" shim declared in include/la_gpu.h.
+ *
+ * Owns the HIP context objects (stream, events, workspace) and sequences the
+ * kernels of one batch; all arithmetic lives in the kernel files.  No host
+ * fallback exists: without a usable gfx950 device la_gpu_open() fails and every
+ * caller above it fails loudly.
+ */
+#include "la_dev.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <new>
+
+struct la_gpu_ctx {
+	int device;
+	hipStream_t own_stream;
+	hipStream_t stream;
+	hipEvent_t ev0, ev1;
+	void *ws;
+	uint64_t ws_bytes;
+	char err[256];
+};
+
+#define HIPCHK(ctx, call)                                                              \
+	do {                                                                           \
+		hipError_t e_ = (call);                                                \
+		if (e_ != hipSuccess) {                                                \
+			snprintf((ctx)->err, sizeof((ctx)->err), "%s: %s", #call,      \
+			    hipGetErrorString(e_));                                    \
+			return LA_ERR_HIP;                                             \
+		}                                                                      \
+	} while (0)
+
+extern "C" {
+
+int la_gpu_abi_version(void) { return LA_GPU_ABI_VERSION; }
+
+int la_gpu_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess)
+		return 0;
+	return n;
+}
+
+int la_gpu_open(int device, la_gpu_ctx **out)
+{
+	if (!out)
+		return LA_ERR_ARG;
+	*out = NULL;
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n)
+		return LA_ERR_NO_DEVICE;
+	la_gpu_ctx *c = new (std::nothrow) la_gpu_ctx();
+	if (!c)
+		return LA_ERR_NOMEM;
+	memset(c, 0, sizeof(*c));
+	c->device = device;
+	if (hipSetDevice(device) != hipSuccess ||
+	    hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
+	    hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+		delete c;
+		return LA_ERR_NO_DEVICE;
+	}
+	c->stream = c->own_stream;
+	*out = c;
+	return LA_OK;
+}
+
+void la_gpu_close(la_gpu_ctx *c)
+{
+	if (!c)
+		return;
+	(void)hipSetDevice(c->device);
+	(void)hipStreamSynchronize(c->stream);
+	if (c->ws) (void)hipFree(c->ws);
+	(void)hipEventDestroy(c->ev0);
+	(void)hipEventDestroy(c->ev1);
+	(void)hipStreamDestroy(c->own_stream);
+	delete c;
+}
+
+int la_gpu_set_stream(la_gpu_ctx *c, void *hip_stream)
+{
+	if (!c) return LA_ERR_ARG;
+	c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+	return LA_OK;
+}
+
+int la_gpu_sync(la_gpu_ctx *c)
+{
+	if (!c) return LA_ERR_ARG;
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	return LA_OK;
+}
+
+const char *la_gpu_last_error(const la_gpu_ctx *c) { return c ? c->err : "no context"; }
+
+int la_gpu_reserve(la_gpu_ctx *c, uint64_t bytes)
+{
+	if (!c) return LA_ERR_ARG;
+	if (bytes <= c->ws_bytes)
+		return LA_OK;
+	HIPCHK(c, hipSetDevice(c->device));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	if (c->ws) { HIPCHK(c, hipFree(c->ws)); c->ws = NULL; c->ws_bytes = 0; }
+	bytes = (bytes + 0xFFFFFull) & ~0xFFFFFull;
+	HIPCHK(c, hipMalloc(&c->ws, bytes));
+	c->ws_bytes = bytes;
+	return LA_OK;
+}
+
+int la_gpu_malloc(la_gpu_ctx *c, void **p, uint64_t bytes)
+{
+	if (!c || !p) return LA_ERR_ARG;
+	HIPCHK(c, hipSetDevice(c->device));
+	HIPCHK(c, hipMalloc(p, bytes ? bytes : 1));
+	return LA_OK;
+}
+int la_gpu_free(la_gpu_ctx *c, void *p)
+{
+	if (!c) return LA_ERR_ARG;
+	if (p) HIPCHK(c, hipFree(p));
+	return LA_OK;
+}
+int la_gpu_malloc_host(la_gpu_ctx *c, void **p, uint64_t bytes)
+{
+	if (!c || !p) return LA_ERR_ARG;
+	HIPCHK(c, hipSetDevice(c->device));
+	HIPCHK(c, hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocDefault));
+	return LA_OK;
+}
+int la_gpu_free_host(la_gpu_ctx *c, void *p)
+{
+	if (!c) return LA_ERR_ARG;
+	if (p) HIPCHK(c, hipHostFree(p));
+	return LA_OK;
+}
+int la_gpu_memcpy_h2d(la_gpu_ctx *c, void *d, const void *h, uint64_t bytes)
+{
+	if (!c) return LA_ERR_ARG;
+	if (bytes) HIPCHK(c, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
+	return LA_OK;
+}
+int la_gpu_memcpy_d2h(la_gpu_ctx *c, void *h, const void *d, uint64_t bytes)
+{
+	if (!c) return LA_ERR_ARG;
+	if (bytes) HIPCHK(c, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream));
+	return LA_OK;
+}
+
+int la_gpu_timer_start(la_gpu_ctx *c)
+{
+	if (!c) return LA_ERR_ARG;
+	HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+	return LA_OK;
+}
+int la_gpu_timer_stop(la_gpu_ctx *c, float *ms)
+{
+	if (!c || !ms) return LA_ERR_ARG;
+	HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+	HIPCHK(c, hipEventSynchronize(c->ev1));
+	HIPCHK(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+	return LA_OK;
+}
+
+/* ------------------------------------------------------------------ hashes */
+
+int la_gpu_xxh32_many(la_gpu_ctx *c, const uint8_t *d_base, const la_hash_job *d_jobs,
+    uint32_t n, uint32_t *d_out)
+{
+	if (!c || (n && (!d_base || !d_jobs || !d_out))) return LA_ERR_ARG;
+	la_launch_xxh32_many(c->stream, d_base, d_jobs, n, d_out);
+	HIPCHK(c, hipGetLastError());
+	return LA_OK;
+}
+
+int la_gpu_crc32_many(la_gpu_ctx *c, const uint8_t *d_base, const la_hash_job *d_jobs,
+    uint32_t n, uint32_t *d_out)
+{
+	if (!c || (n && (!d_base || !d_jobs || !d_out))) return LA_ERR_ARG;
+	la_launch_crc32_many(c->stream, d_base, d_jobs, n, d_out);
+	HIPCHK(c, hipGetLastError());
+	return LA_OK;
+}
+
+/* ------------------------------------------------------------------ lz4 */
+
+static uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) & ~(a - 1); }
+
+uint64_t la_gpu_lz4_workspace_bytes(uint32_t n_blocks, uint64_t src_bytes)
+{
+	(void)src_bytes;
+	uint64_t b = 0;
+	b += align_up((uint64_t)n_blocks * sizeof(uint32_t), 256);	/* nseq */
+	b += align_up(la_scan_scratch_bytes(n_blocks), 256);
+	return b + 4096;
+}
+
+int la_gpu_lz4_decode(la_gpu_ctx *c, const la_lz4_batch *bt)
+{
+	if (!c || !bt)
+		return LA_ERR_ARG;
+	if (bt->n_blocks && (!bt->d_src || !bt->d_blocks || !bt->d_dst || !bt->d_out_len ||
+	    !bt->d_dst_off || !bt->d_block_status))
+		return LA_ERR_ARG;
+	if (bt->n_frames && (!bt->d_frames || !bt->d_frame_status))
+		return LA_ERR_ARG;
+	if (!bt->d_dst_off)
+		return LA_ERR_ARG;
+	uint64_t need = la_gpu_lz4_workspace_bytes(bt->n_blocks, bt->src_bytes);
+	if (need > c->ws_bytes) {
+		int rc = la_gpu_reserve(c, need);
+		if (rc != LA_OK) return rc;
+	}
+	hipStream_t s = c->stream;
+	uint8_t *ws = (uint8_t *)c->ws;
+	uint32_t *d_nseq = (uint32_t *)ws;
+	void *d_scan = ws + align_up((uint64_t)bt->n_blocks * sizeof(uint32_t), 256);
+	const bool verify = !(bt->options & LA_LZ4_OPT_NO_VERIFY);
+
+	if (bt->n_blocks)
+		HIPCHK(c, hipMemsetAsync(bt->d_block_status, 0, (size_t)bt->n_blocks * sizeof(uint32_t), s));
+	if (verify)
+		la_launch_lz4_block_sums(s, bt->d_src, bt->d_blocks, bt->n_blocks, bt->d_block_status);
+	la_launch_lz4_measure(s, bt->d_src, bt->d_blocks, bt->n_blocks, bt->d_out_len, d_nseq, bt->d_block_status);
+	la_launch_scan_u32(s, bt->d_out_len, bt->n_blocks, bt->d_dst_off, d_scan);
+	la_launch_lz4_expand_general(s, bt->d_src, bt->src_bytes, bt->d_blocks, bt->n_blocks, bt->d_dst,
+	    bt->dst_cap, bt->d_dst_off, bt->d_out_len, bt->d_block_status);
+	if (bt->n_frames) {
+		if (verify)
+			la_launch_lz4_frame_sums(s, bt->d_src, bt->d_dst, bt->d_frames, bt->n_frames,
+			    bt->d_dst_off, bt->dst_cap, bt->d_frame_status);
+		else
+			HIPCHK(c, hipMemsetAsync(bt->d_frame_status, 0, (size_t)bt->n_frames * sizeof(uint32_t), s));
+	}
+	if (bt->d_summary)
+		la_launch_lz4_summary(s, bt->d_out_len, bt->d_block_status, bt->n_blocks,
+		    bt->d_frame_status, bt->n_frames, bt->d_dst_off, bt->d_summary);
+	HIPCHK(c, hipGetLastError());
+	return LA_OK;
+}
+
+int la_gpu_gzip_decode(la_gpu_ctx *c, const la_gz_batch *bt)
+{
+	if (!c || !bt)
+		return LA_ERR_ARG;
+	snprintf(c->err, sizeof(c->err), "la_gpu_gzip_decode: deflate kernels not built into this library yet");
+	return LA_ERR_ARG;
+}
+
+} /* extern "C" */

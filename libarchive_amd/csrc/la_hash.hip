@@ -1,0 +1,233 @@
+/*
+ * la_hash.hip -- many-hash XXH32 and wave-reduced CRC32 kernels (gfx950).
+ *
+ * Replaces, for whole batches, the per-call hashing of
+ *   libarchive/xxhash.c:234-319        (XXH32 one shot; call sites lz4.c:446, :518, :652)
+ *   libarchive/archive_crc32.h:43-84   (crc32; the gzip trailer value the reference
+ *                                       never checks, gzip.c:423)
+ * Integer/byte work bound by HBM reads of the hashed bytes; no MFMA.
+ *
+ * XXH32 is a serial chain per hash, so the parallel axis is "many
+ * hashes": one lane owns one hash and streams its range with 16-byte loads.
+ * CRC32 is GF(2)-linear, so ONE range is split over the 64 lanes of a wave
+ * (contiguous chunks, slicing-by-4 tables in LDS) and the lane values are
+ * merged with a log2(64)-step shuffle tree of carry-less multiplications by
+ * x^(8*chunk*2^k) mod P.
+ */
+#include "la_dev.h"
+
+/* ------------------------------------------------------------------ XXH32 */
+
+__global__ __launch_bounds__(256) void xxh32_many_kernel(const uint8_t *__restrict__ base,
+    const la_hash_job *__restrict__ jobs, uint32_t n, uint32_t *__restrict__ out)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n)
+		return;
+	la_hash_job j = jobs[i];
+	out[i] = xxh32_lane(base + j.off, j.len, j.seed);
+}
+
+/* block checksums: XXH32 over the compressed payload (lz4.c:517-526) */
+__global__ __launch_bounds__(256) void lz4_block_sums_kernel(const uint8_t *__restrict__ src,
+    const la_lz4_block *__restrict__ blocks, uint32_t n, uint32_t *__restrict__ status)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n)
+		return;
+	la_lz4_block b = blocks[i];
+	if (!(b.flags & LA_LZ4B_CHECKSUM))
+		return;
+	uint32_t h = xxh32_lane(src + b.src_off, b.src_len, 0);
+	if (h != b.block_sum)
+		status[i] = LA_ST_LZ4_BAD_BLOCK_SUM;	/* outranks a decode failure: checked first, lz4.c:517 vs :594 */
+}
+
+/* per frame: descriptor check byte (lz4.c:446-451) and content checksum over the
+ * frame's decoded bytes (lz4.c:639-665) */
+__global__ __launch_bounds__(64) void lz4_frame_sums_kernel(const uint8_t *__restrict__ src,
+    const uint8_t *__restrict__ dst, const la_lz4_frame *__restrict__ frames, uint32_t n,
+    const uint64_t *__restrict__ dst_off, uint64_t dst_cap, uint32_t *__restrict__ fstatus)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n)
+		return;
+	la_lz4_frame f = frames[i];
+	uint32_t st = LA_ST_OK;
+	if (f.flags & LA_LZ4F_HEADER_SUM) {
+		uint32_t h = xxh32_lane(src + f.desc_off, f.desc_len - 1, 0);
+		if (((h >> 8) & 0xff) != src[f.desc_off + f.desc_len - 1])
+			st = LA_ST_LZ4_BAD_HEADER_SUM;
+	}
+	if (st == LA_ST_OK && (f.flags & LA_LZ4F_CONTENT_SUM)) {
+		uint64_t a = dst_off[f.first_block], e = dst_off[f.first_block + f.n_blocks];
+		/* xxhash.c:234: the length is an unsigned int there */
+		if (e <= dst_cap) {
+			uint32_t h = xxh32_lane(dst + a, (uint32_t)(e - a), 0);
+			if (h != f.content_sum)
+				st = LA_ST_LZ4_BAD_CONTENT_SUM;
+		}
+	}
+	fstatus[i] = st;
+}
+
+void la_launch_xxh32_many(hipStream_t s, const uint8_t *d_base, const la_hash_job *d_jobs,
+    uint32_t n, uint32_t *d_out)
+{
+	if (n == 0) return;
+	hipLaunchKernelGGL(xxh32_many_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_base, d_jobs, n, d_out);
+}
+
+void la_launch_lz4_block_sums(hipStream_t s, const uint8_t *d_src, const la_lz4_block *d_blocks,
+    uint32_t n, uint32_t *d_status)
+{
+	if (n == 0) return;
+	hipLaunchKernelGGL(lz4_block_sums_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_src, d_blocks, n, d_status);
+}
+
+void la_launch_lz4_frame_sums(hipStream_t s, const uint8_t *d_src, const uint8_t *d_dst,
+    const la_lz4_frame *d_frames, uint32_t n_frames, const uint64_t *d_dst_off, uint64_t dst_cap,
+    uint32_t *d_frame_status)
+{
+	if (n_frames == 0) return;
+	hipLaunchKernelGGL(lz4_frame_sums_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, s,
+	    d_src, d_dst, d_frames, n_frames, d_dst_off, dst_cap, d_frame_status);
+}
+
+/* ------------------------------------------------------------------ CRC32 */
+
+#define CRC_POLY 0xEDB88320u
+
+/* a(x)*b(x) mod P(x), reflected bit order (bit 31 = x^0) */
+__device__ __forceinline__ uint32_t gf2_mulmod(uint32_t a, uint32_t b)
+{
+	uint32_t r = 0;
+#pragma unroll 8
+	for (int i = 0; i < 32; i++) {
+		r ^= b & (0u - (a >> 31));
+		a <<= 1;
+		b = (b >> 1) ^ (CRC_POLY & (0u - (b & 1)));
+	}
+	return r;
+}
+
+/* x^(8*nbytes) mod P */
+__device__ uint32_t gf2_xpow8(uint32_t nbytes)
+{
+	uint32_t result = 0x80000000u, base = 0x00800000u;
+	while (nbytes) {
+		if (nbytes & 1)
+			result = gf2_mulmod(result, base);
+		base = gf2_mulmod(base, base);
+		nbytes >>= 1;
+	}
+	return result;
+}
+
+/* slicing-by-4 tables in LDS: T[k][b] = state reached from byte b followed by k zero bytes */
+__device__ __forceinline__ void crc_build_tables(uint32_t *T /* [4][256] */)
+{
+	for (uint32_t b = threadIdx.x; b < 256; b += blockDim.x) {
+		uint32_t c = b;
+		for (int k = 0; k < 8; k++)
+			c = (c >> 1) ^ (CRC_POLY & (0u - (c & 1)));
+		T[b] = c;
+	}
+	__syncthreads();
+	for (uint32_t b = threadIdx.x; b < 256; b += blockDim.x) {
+		uint32_t c = T[b];
+		for (int k = 1; k < 4; k++) {
+			c = T[c & 0xff] ^ (c >> 8);
+			T[k * 256 + b] = c;
+		}
+	}
+	__syncthreads();
+}
+
+/* raw CRC state update (no pre/post inversion) over n bytes by one lane */
+__device__ __forceinline__ uint32_t crc_run(const uint32_t *T, uint32_t state, const uint8_t *p, uint32_t n)
+{
+	while (n && ((uintptr_t)p & 3)) {
+		state = T[(state ^ *p++) & 0xff] ^ (state >> 8);
+		n--;
+	}
+	while (n >= 16) {
+		uint4 v = *(const uint4 *)__builtin_assume_aligned(p, 4);
+		uint32_t w[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			uint32_t x = state ^ w[k];
+			state = T[768 + (x & 0xff)] ^ T[512 + ((x >> 8) & 0xff)] ^
+			    T[256 + ((x >> 16) & 0xff)] ^ T[x >> 24];
+		}
+		p += 16; n -= 16;
+	}
+	while (n >= 4) {
+		uint32_t x = state ^ *(const uint32_t *)p;
+		state = T[768 + (x & 0xff)] ^ T[512 + ((x >> 8) & 0xff)] ^
+		    T[256 + ((x >> 16) & 0xff)] ^ T[x >> 24];
+		p += 4; n -= 4;
+	}
+	while (n--)
+		state = T[(state ^ *p++) & 0xff] ^ (state >> 8);
+	return state;
+}
+
+/*
+ * One wave per range.  The range is laid out right-aligned in 64 virtual
+ * chunks of S bytes (S a multiple of 16); lane i owns chunk i.  The lane that
+ * holds the first real byte starts from the real initial state (seed ^ ~0),
+ * every later lane from state 0, earlier lanes hold state 0 and no bytes.
+ * Because the update is linear over GF(2), the state after the whole range is
+ *     sum_i  state_i * x^(8 * S * (63 - i))      (mod P)
+ * which the shuffle tree evaluates in 6 steps.
+ */
+__device__ __forceinline__ uint32_t crc32_wave(const uint32_t *T, const uint8_t *p, uint32_t len,
+    uint32_t seed, int lane)
+{
+	if (len == 0)
+		return seed;
+	uint32_t S = ((len + 63) / 64 + 15) & ~15u;
+	uint64_t pad = 64ull * S - len;		/* virtual bytes in front of the range */
+	uint32_t f = (uint32_t)(pad / S);	/* lane holding the first real byte */
+	uint64_t vbeg = (uint64_t)lane * S, vend = vbeg + S;
+	uint32_t state = 0;
+	if ((uint32_t)lane >= f) {
+		uint64_t lo = vbeg < pad ? pad : vbeg;
+		uint32_t init = ((uint32_t)lane == f) ? (seed ^ 0xFFFFFFFFu) : 0u;
+		state = crc_run(T, init, p + (lo - pad), (uint32_t)(vend - lo));
+	}
+	uint32_t g = gf2_xpow8(S);
+#pragma unroll
+	for (int k = 0; k < 6; k++) {
+		uint32_t right = __shfl_down(state, 1 << k, 64);
+		state = gf2_mulmod(state, g) ^ right;
+		g = gf2_mulmod(g, g);
+	}
+	return state ^ 0xFFFFFFFFu;	/* valid in lane 0 */
+}
+
+__global__ __launch_bounds__(256) void crc32_many_kernel(const uint8_t *__restrict__ base,
+    const la_hash_job *__restrict__ jobs, uint32_t n, uint32_t *__restrict__ out)
+{
+	__shared__ uint32_t T[4 * 256];
+	crc_build_tables(T);
+	int lane = threadIdx.x & 63;
+	uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+	for (uint32_t i = wave; i < n; i += nwaves) {
+		la_hash_job j = jobs[i];
+		uint32_t c = crc32_wave(T, base + j.off, j.len, j.seed, lane);
+		if (lane == 0)
+			out[i] = c;
+	}
+}
+
+void la_launch_crc32_many(hipStream_t s, const uint8_t *d_base, const la_hash_job *d_jobs,
+    uint32_t n, uint32_t *d_out)
+{
+	if (n == 0) return;
+	uint32_t blocks = (n + 3) / 4;
+	if (blocks > 256 * 8) blocks = 256 * 8;
+	hipLaunchKernelGGL(crc32_many_kernel, dim3(blocks), dim3(256), 0, s, d_base, d_jobs, n, d_out);
+}

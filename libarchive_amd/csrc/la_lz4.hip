@@ -1,0 +1,290 @@
+/*
+ * la_lz4.hip -- LZ4 block decode kernels (gfx950).
+ *
+ * Replaces liblz4's LZ4_decompress_safe / LZ4_decompress_safe_usingDict as
+ * called by libarchive/archive_read_support_filter_lz4.c:557-591 and :711, for a
+ * whole table of blocks per launch.  Byte/integer work, HBM-bound; no MFMA.
+ *
+ * Two phases, because a block's decoded length is not in the frame:
+ *   1. measure  -- one LANE per block walks the token chain (serial pointer
+ *      chase, 64 chains per wave), applies every accept/reject rule of the
+ *      library's safe decoder and reports decoded length + sequence count.
+ *      An exclusive scan of the lengths (la_scan.hip) then packs the blocks
+ *      back to back in the decoded slab.
+ *   2. expand   -- copies literals and matches into the slab.
+ *        general kernel (this file): one WAVE per block (or per chain of
+ *        dependent blocks); token chain kept wave-uniform in SGPRs and fed from
+ *        a 512-byte register window of the compressed payload via v_readlane;
+ *        literal and match copies are wave-wide (64 bytes per step), matches
+ *        read the already written slab.  Handles every block size (64 KiB..4 MiB,
+ *        8 MiB legacy), stored blocks and dependent blocks.
+ *        fast kernel (la_lz4_fast.hip): 64 KiB independent blocks through an LDS
+ *        output window.
+ */
+#include "la_dev.h"
+
+#define LZ4_MFLIMIT 12
+#define LZ4_LASTLIT 5
+
+/* ------------------------------------------------------------------ measure */
+
+/*
+ * Accept/reject rules = liblz4 1.9.3 safe decoder (see oracle/orc_lz4.c for
+ * the derivation): exact input consumption, last-sequence rules relative to
+ * the destination CAPACITY, match end margin, offset range, bounded length
+ * extensions; offset 0 rejected.
+ */
+__global__ __launch_bounds__(256) void lz4_measure_kernel(const uint8_t *__restrict__ src,
+    const la_lz4_block *__restrict__ blocks, uint32_t n, uint32_t *__restrict__ out_len,
+    uint32_t *__restrict__ nseq_out, uint32_t *__restrict__ status)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n)
+		return;
+	la_lz4_block b = blocks[i];
+	if (status[i] != LA_ST_OK) {	/* block checksum already failed */
+		out_len[i] = 0;
+		if (nseq_out) nseq_out[i] = 0;
+		return;
+	}
+	if (b.flags & LA_LZ4B_STORED) {
+		out_len[i] = b.src_len;
+		if (nseq_out) nseq_out[i] = 0;
+		return;
+	}
+	const uint8_t *s = src + b.src_off;
+	const int iend = (int)b.src_len;
+	const int oend = (int)b.dst_cap;
+	const int dict = (b.flags & LA_LZ4B_DEPENDENT) ? 65536 : 0;	/* lz4.c:563-584: any offset reaches the zero-filled prefix */
+	int ip = 0, op = 0;
+	uint32_t nseq = 0;
+	bool ok = iend > 0;
+
+	while (ok) {
+		uint32_t token = s[ip++];
+		int length = (int)(token >> 4);
+		if (length == 15) {
+			if (ip >= iend - 15) { ok = false; break; }
+			uint32_t x;
+			do {
+				x = s[ip++];
+				length += (int)x;
+				if (ip >= iend - 15)
+					break;
+			} while (x == 255);
+		}
+		nseq++;
+		if (op + length > oend - LZ4_MFLIMIT || ip + length > iend - (2 + 1 + LZ4_LASTLIT)) {
+			if (ip + length != iend || op + length > oend)
+				ok = false;
+			op += length;
+			break;
+		}
+		ip += length;
+		op += length;
+		int offset = (int)s[ip] | ((int)s[ip + 1] << 8);
+		ip += 2;
+		length = (int)(token & 15);
+		if (length == 15) {
+			uint32_t x;
+			do {
+				x = s[ip++];
+				length += (int)x;
+				if (ip >= iend - LZ4_LASTLIT + 1) { ok = false; break; }
+			} while (x == 255);
+			if (!ok) break;
+		}
+		length += 4;
+		if (offset == 0 || offset > op + dict || op + length > oend - LZ4_LASTLIT) { ok = false; break; }
+		op += length;
+	}
+	out_len[i] = ok ? (uint32_t)op : 0u;
+	if (nseq_out) nseq_out[i] = ok ? nseq : 0u;
+	if (!ok)
+		status[i] = LA_ST_LZ4_DECODE;
+}
+
+void la_launch_lz4_measure(hipStream_t s, const uint8_t *d_src, const la_lz4_block *d_blocks,
+    uint32_t n, uint32_t *d_out_len, uint32_t *d_nseq, uint32_t *d_status)
+{
+	if (n == 0) return;
+	hipLaunchKernelGGL(lz4_measure_kernel, dim3((n + 255) / 256), dim3(256), 0, s,
+	    d_src, d_blocks, n, d_out_len, d_nseq, d_status);
+}
+
+/* ------------------------------------------------------------------ general expand */
+
+/* 512-byte register window over the compressed payload: lane l holds the
+ * aligned dwords at base+4l (w0) and base+256+4l (w1). */
+struct src_window {
+	const uint8_t *base;	/* 4-byte aligned, wave-uniform */
+	const uint8_t *limit;	/* one past the last readable byte of the whole source image */
+	uint32_t w0, w1;
+};
+
+__device__ __forceinline__ uint32_t win_load(const src_window &W, const uint8_t *p)
+{
+	/* p is 4-aligned.  A dword that holds at least one byte of the image lies in
+	 * the same page as that byte, so loading it whole cannot fault; dwords
+	 * entirely past the image are never touched. */
+	return (p < W.limit) ? *(const uint32_t *)p : 0u;
+}
+
+__device__ __forceinline__ void win_reset(src_window &W, const uint8_t *q, int lane)
+{
+	W.base = (const uint8_t *)((uintptr_t)q & ~(uintptr_t)3);
+	W.w0 = win_load(W, W.base + 4 * lane);
+	W.w1 = win_load(W, W.base + 256 + 4 * lane);
+}
+
+/* byte at q (wave-uniform address, q >= W.base) */
+__device__ __forceinline__ uint32_t win_byte(src_window &W, const uint8_t *q, int lane)
+{
+	uint32_t d = (uint32_t)(q - W.base);
+	if (d >= 256) {
+		if (d < 512) {
+			W.base += 256;
+			W.w0 = W.w1;
+			W.w1 = win_load(W, W.base + 256 + 4 * lane);
+			d -= 256;
+		} else {
+			win_reset(W, q, lane);
+			d = (uint32_t)(q - W.base);
+		}
+	}
+	uint32_t dw = (uint32_t)__builtin_amdgcn_readlane((int)W.w0, (int)(d >> 2));
+	return (dw >> ((d & 3) * 8)) & 0xffu;
+}
+
+__device__ __forceinline__ void wave_mem_fence()
+{
+	/* make this wave's earlier global stores visible to its own later loads
+	 * (same CU, same L1): s_waitcnt vmcnt(0) is all the hardware needs */
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+/*
+ * Decode one validated block with one wave.  d points at the block's slot in
+ * the slab; bytes d[-dict_len..0) are the previous block (dependent frames),
+ * anything further back reads as zero (the reference keeps only the previous
+ * block in its 64 KiB prefix and zero-fills the rest, lz4.c:563-577).
+ */
+__device__ void lz4_expand_block_wave(const uint8_t *s, uint32_t src_len, const uint8_t *src_limit,
+    uint8_t *d, uint32_t dict_len, int lane)
+{
+	src_window W;
+	W.limit = src_limit;
+	win_reset(W, s, lane);
+	const uint8_t *ip = s;
+	const uint8_t *iend = s + src_len;
+	uint32_t op = 0;
+	uint32_t visible = 0;	/* output bytes [0, visible) are known to be visible to loads */
+
+	for (;;) {
+		uint32_t token = win_byte(W, ip++, lane);
+		uint32_t lit = token >> 4;
+		if (lit == 15) {
+			uint32_t x;
+			do {
+				x = win_byte(W, ip++, lane);
+				lit += x;
+			} while (x == 255);
+		}
+		/* literals: 64 bytes per step, coalesced */
+		for (uint32_t j = (uint32_t)lane; j < lit; j += LA_WAVE)
+			d[op + j] = ip[j];
+		ip += lit;
+		op += lit;
+		if (ip >= iend)
+			break;
+		uint32_t off = win_byte(W, ip, lane) | (win_byte(W, ip + 1, lane) << 8);
+		ip += 2;
+		uint32_t ml = token & 15;
+		if (ml == 15) {
+			uint32_t x;
+			do {
+				x = win_byte(W, ip++, lane);
+				ml += x;
+			} while (x == 255);
+		}
+		ml += 4;
+
+		/* Source bytes are [op-off, op-off+min(ml,off)); with the modulo form
+		 * every source byte lies below op, i.e. was stored by an EARLIER
+		 * instruction of this wave.  Fence only if some of it is newer than
+		 * the last fence. */
+		uint32_t span = ml < off ? ml : off;
+		if (op > visible && (int64_t)op - (int64_t)off + (int64_t)span > (int64_t)visible) {
+			wave_mem_fence();
+			visible = op;
+		}
+		for (uint32_t j = (uint32_t)lane; j < ml; j += LA_WAVE) {
+			uint32_t k = (off < ml) ? (j % off) : j;
+			int64_t from = (int64_t)op - (int64_t)off + (int64_t)k;
+			uint8_t v;
+			if (from >= 0 || (uint64_t)(-from) <= dict_len)
+				v = d[from];
+			else
+				v = 0;
+			d[op + j] = v;
+		}
+		op += ml;
+	}
+}
+
+__global__ __launch_bounds__(256) void lz4_expand_general_kernel(const uint8_t *__restrict__ src,
+    uint64_t src_bytes, const la_lz4_block *__restrict__ blocks, uint32_t n, uint8_t *dst,
+    uint64_t dst_cap, const uint64_t *__restrict__ dst_off, const uint32_t *__restrict__ out_len,
+    const uint32_t *__restrict__ status)
+{
+	int lane = threadIdx.x & 63;
+	uint32_t i = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+	if (i >= n)
+		return;
+	uint32_t fl = blocks[i].flags;
+	/* a dependent block that is not the first of its frame belongs to the
+	 * chain of the wave that owns the frame's first block */
+	if ((fl & LA_LZ4B_DEPENDENT) && !(fl & LA_LZ4B_FIRST))
+		return;
+	const uint8_t *src_limit = src + src_bytes;
+	uint32_t prev_len = 0;
+	for (;;) {
+		la_lz4_block b = blocks[i];
+		uint8_t *d = dst + dst_off[i];
+		uint32_t olen = out_len[i];
+		/* never write past the slab, whatever the tables say */
+		if (status[i] == LA_ST_OK && olen > 0 && dst_off[i] + olen <= dst_cap) {
+			const uint8_t *s = src + b.src_off;
+			if (b.flags & LA_LZ4B_STORED) {
+				for (uint32_t j = (uint32_t)lane; j < b.src_len; j += LA_WAVE)
+					d[j] = s[j];
+			} else {
+				uint32_t dict_len = 0;
+				if ((b.flags & LA_LZ4B_DEPENDENT) && !(b.flags & LA_LZ4B_FIRST))
+					dict_len = prev_len < 65536u ? prev_len : 65536u;
+				lz4_expand_block_wave(s, b.src_len, src_limit, d, dict_len, lane);
+			}
+		}
+		if (!(b.flags & LA_LZ4B_DEPENDENT))
+			break;
+		/* next block of the chain */
+		prev_len = olen;
+		i++;
+		if (i >= n)
+			break;
+		uint32_t nf = blocks[i].flags;
+		if (!(nf & LA_LZ4B_DEPENDENT) || (nf & LA_LZ4B_FIRST))
+			break;
+		wave_mem_fence();	/* previous block's bytes become the dictionary */
+	}
+}
+
+void la_launch_lz4_expand_general(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
+    const la_lz4_block *d_blocks, uint32_t n, uint8_t *d_dst, uint64_t dst_cap,
+    const uint64_t *d_dst_off, const uint32_t *d_out_len, const uint32_t *d_status)
+{
+	if (n == 0) return;
+	hipLaunchKernelGGL(lz4_expand_general_kernel, dim3((n + 3) / 4), dim3(256), 0, s,
+	    d_src, src_bytes, d_blocks, n, d_dst, dst_cap, d_dst_off, d_out_len, d_status);
+}

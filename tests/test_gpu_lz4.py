@@ -1,0 +1,134 @@
+"""GPU parity (run with -m gpu on the MI355X box): the HIP lz4 path through the C ABI
+(la_gpu_lz4_decode) against the oracle on the same inputs -- bit exact."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import streams as S
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_fixtures")
+MANIFEST = [e for e in json.load(open(os.path.join(GOLD, "manifest.json"))) if e["codec"] == "lz4"]
+
+
+def gpu_decode(ctx, image, options=0):
+    from libarchive_amd.lz4 import decode_image
+    out, rc, msg, plan = decode_image(ctx, image, options=options)
+    return out.tobytes(), rc, msg
+
+
+def test_library_is_loaded_and_device_present(gpu_ctx):
+    import libarchive_amd as la
+    assert la.gpu_lib().la_gpu_abi_version() == 1
+    assert la.gpu_lib().la_gpu_device_count() >= 1
+
+
+@pytest.mark.parametrize("name", sorted(S.appendix_d_lz4_cases()))
+def test_behaviour_table(gpu_ctx, name):
+    img, want, rc, msg = S.appendix_d_lz4_cases()[name]
+    assert gpu_decode(gpu_ctx, img) == (want, rc, msg)
+
+
+@pytest.mark.parametrize("entry", MANIFEST, ids=[e["file"] for e in MANIFEST])
+def test_reference_fixtures(gpu_ctx, entry):
+    import hashlib
+    data = open(os.path.join(GOLD, entry["file"]), "rb").read()
+    out, rc, msg = gpu_decode(gpu_ctx, data)
+    assert rc == 0 and len(out) == entry["decoded_size"]
+    assert hashlib.sha256(out).hexdigest() == entry["decoded_sha256"]
+
+
+def test_synthetic_many_block_stream(gpu_ctx):
+    img, plain = S.synth_lz4_stream(0x4C413335, 0, 64, blocks_per_frame=16, block_size=65536)
+    out, rc, msg = gpu_decode(gpu_ctx, img)
+    assert rc == 0 and msg == ""
+    assert out == plain.tobytes()
+    ref, res = O.lz4_stream_decode(img, plain.size + 16)
+    assert res.rc == 0 and ref.tobytes() == out
+
+
+def test_ragged_block_sizes(gpu_ctx):
+    for bs in (1, 13, 64, 65, 4095, 65535):
+        img, plain = S.synth_lz4_stream(77, 0, 3, blocks_per_frame=5, block_size=bs, nthreads=1)
+        out, rc, msg = gpu_decode(gpu_ctx, img)
+        assert (rc, msg) == (0, "") and out == plain.tobytes(), bs
+
+
+def test_real_compressor_blocks_and_overlaps(gpu_ctx):
+    rnd = random.Random(21)
+    words = [rnd.randbytes(rnd.randint(1, 12)) for _ in range(30)]
+    blocks = []
+    for k in range(40):
+        n = rnd.randint(1, 65536)
+        kind = k % 4
+        if kind == 0:
+            d = b"".join(rnd.choice(words) for _ in range(n // 5 + 1))[:n]
+        elif kind == 1:
+            d = bytes([k]) * n                      # offset-1 RLE
+        elif kind == 2:
+            d = (b"ab" * n)[:n]                     # offset-2 overlap
+        else:
+            d = rnd.randbytes(n)                    # incompressible
+        blocks.append((d, S.lz4_block(S.lz4_compress_block(d), bsum=True)))
+    img, plain = S.lz4_frame(blocks, flg=0x74)
+    out, rc, msg = gpu_decode(gpu_ctx, img)
+    assert (rc, msg) == (0, "") and out == plain
+
+
+def test_dependent_blocks(gpu_ctx):
+    chunks = [bytes(range(256)) * 3, b"hello world " * 20, b"x" * 100, b"tail" * 50]
+    img, plain = S.lz4_dependent_frame(chunks)
+    assert gpu_decode(gpu_ctx, img) == (plain, 0, "")
+
+
+def test_error_order_in_a_long_stream(gpu_ctx):
+    img, plain = S.synth_lz4_stream(5, 0, 8, blocks_per_frame=4, block_size=8192, nthreads=2)
+    import libarchive_amd as la
+    idx = la.lz4_index(img)
+    b = idx.blocks[13]
+    m = img.copy()
+    m[int(b["src_off"]) + 5] ^= 0x40            # corrupt block 13: its block checksum fails first
+    out, rc, msg = gpu_decode(gpu_ctx, m)
+    assert (rc, msg) == (-30, "malformed lz4 data") and out == plain.tobytes()[:13 * 8192]
+    ref, res = O.lz4_stream_decode(m, plain.size + 16)
+    assert (ref.tobytes(), res.rc, res.errmsg.decode()) == (out, rc, msg)
+
+
+def test_mutated_streams(gpu_ctx):
+    rnd = random.Random(3)
+    base, _ = S.synth_lz4_stream(9, 0, 2, blocks_per_frame=3, block_size=2048, nthreads=1)
+    base = base.tobytes()
+    for t in range(60):
+        m = bytearray(base)
+        for _ in range(rnd.randint(1, 3)):
+            m[rnd.randrange(len(m))] = rnd.getrandbits(8)
+        if rnd.random() < 0.3:
+            m = m[:rnd.randrange(1, len(m))]
+        m = bytes(m)
+        ref, res = O.lz4_stream_decode(m, 1 << 22)
+        assert gpu_decode(gpu_ctx, m) == (ref.tobytes(), res.rc, res.errmsg.decode()), t
+
+
+def test_mutated_blocks_without_checksums(gpu_ctx):
+    """Corrupt payloads in frames WITHOUT block checksums so that the decoder's own
+    accept/reject rules decide (and nothing may be written outside a block's window)."""
+    rnd = random.Random(8)
+    words = [rnd.randbytes(rnd.randint(1, 9)) for _ in range(20)]
+    for t in range(40):
+        blocks = []
+        for k in range(6):
+            n = rnd.randint(20, 3000)
+            d = b"".join(rnd.choice(words) for _ in range(n // 4 + 1))[:n]
+            c = bytearray(S.lz4_compress_block(d))
+            if k == 3:
+                for _ in range(rnd.randint(1, 3)):
+                    c[rnd.randrange(len(c))] = rnd.getrandbits(8)
+            blocks.append((d, S.lz4_block(bytes(c))))
+        img, _ = S.lz4_frame(blocks, flg=0x60)
+        ref, res = O.lz4_stream_decode(img, 1 << 22)
+        assert gpu_decode(gpu_ctx, img) == (ref.tobytes(), res.rc, res.errmsg.decode()), t
