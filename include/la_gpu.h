@@ -64,6 +64,13 @@ int         la_gpu_memcpy_d2h(la_gpu_ctx *ctx, void *h_dst, const void *d_src, u
 int         la_gpu_timer_start(la_gpu_ctx *ctx);
 int         la_gpu_timer_stop(la_gpu_ctx *ctx, float *elapsed_ms);	/* synchronises */
 
+/* Per-phase timing of the most recent batch call (HIP events between the kernels,
+ * on the work stream).  la_gpu_profile_read() synchronises on the last event and
+ * returns the number of phases filled in (0 when profiling is off). */
+#define LA_PROF_MAX_PHASES 12
+int         la_gpu_profile_enable(la_gpu_ctx *ctx, int on);
+int         la_gpu_profile_read(la_gpu_ctx *ctx, float *ms, const char **names, int cap);
+
 /* ---- per-unit status words written by the device ---- */
 enum {
 	LA_ST_OK                  = 0,

@@ -97,6 +97,8 @@ def gpu_lib():
         lib.la_gpu_reserve.argtypes = [C.c_void_p, C.c_uint64]
         lib.la_gpu_timer_start.argtypes = [C.c_void_p]
         lib.la_gpu_timer_stop.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        lib.la_gpu_profile_enable.argtypes = [C.c_void_p, C.c_int]
+        lib.la_gpu_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_char_p), C.c_int]
         lib.la_gpu_xxh32_many.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         lib.la_gpu_crc32_many.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         lib.la_gpu_lz4_workspace_bytes.argtypes = [C.c_uint32, C.c_uint64]
@@ -202,6 +204,18 @@ class GpuContext:
         ms = C.c_float()
         self._check(gpu_lib().la_gpu_timer_stop(self._h, C.byref(ms)), "la_gpu_timer_stop")
         return ms.value
+
+    def profile_enable(self, on=True):
+        self._check(gpu_lib().la_gpu_profile_enable(self._h, 1 if on else 0), "la_gpu_profile_enable")
+
+    def profile_read(self):
+        """{phase name: ms} of the most recent batch call (synchronises)."""
+        ms = (C.c_float * 12)()
+        names = (C.c_char_p * 12)()
+        n = gpu_lib().la_gpu_profile_read(self._h, ms, names, 12)
+        if n < 0:
+            self._check(n, "la_gpu_profile_read")
+        return [(names[i].decode(), float(ms[i])) for i in range(n)]
 
     def xxh32_many(self, d_base_ptr, d_jobs_ptr, n, d_out_ptr):
         self._check(gpu_lib().la_gpu_xxh32_many(self._h, d_base_ptr, d_jobs_ptr, n, d_out_ptr), "la_gpu_xxh32_many")

@@ -19,8 +19,28 @@ struct la_gpu_ctx {
 	hipEvent_t ev0, ev1;
 	void *ws;
 	uint64_t ws_bytes;
+	/* optional per-phase timing of the last batch (HIP events on the work stream) */
+	int prof_on;
+	int prof_n;
+	hipEvent_t prof_ev[LA_PROF_MAX_PHASES + 1];
+	const char *prof_name[LA_PROF_MAX_PHASES];
 	char err[256];
 };
+
+static void prof_begin(la_gpu_ctx *c)
+{
+	c->prof_n = 0;
+	if (c->prof_on)
+		(void)hipEventRecord(c->prof_ev[0], c->stream);
+}
+static void prof_mark(la_gpu_ctx *c, const char *name)
+{
+	if (!c->prof_on || c->prof_n >= LA_PROF_MAX_PHASES)
+		return;
+	c->prof_name[c->prof_n] = name;
+	c->prof_n++;
+	(void)hipEventRecord(c->prof_ev[c->prof_n], c->stream);
+}
 
 #define HIPCHK(ctx, call)                                                              \
 	do {                                                                           \
@@ -63,6 +83,8 @@ int la_gpu_open(int device, la_gpu_ctx **out)
 		delete c;
 		return LA_ERR_NO_DEVICE;
 	}
+	for (int i = 0; i <= LA_PROF_MAX_PHASES; i++)
+		(void)hipEventCreate(&c->prof_ev[i]);
 	c->stream = c->own_stream;
 	*out = c;
 	return LA_OK;
@@ -77,6 +99,8 @@ void la_gpu_close(la_gpu_ctx *c)
 	if (c->ws) (void)hipFree(c->ws);
 	(void)hipEventDestroy(c->ev0);
 	(void)hipEventDestroy(c->ev1);
+	for (int i = 0; i <= LA_PROF_MAX_PHASES; i++)
+		(void)hipEventDestroy(c->prof_ev[i]);
 	(void)hipStreamDestroy(c->own_stream);
 	delete c;
 }
@@ -165,6 +189,28 @@ int la_gpu_timer_stop(la_gpu_ctx *c, float *ms)
 	return LA_OK;
 }
 
+int la_gpu_profile_enable(la_gpu_ctx *c, int on)
+{
+	if (!c) return LA_ERR_ARG;
+	c->prof_on = on ? 1 : 0;
+	c->prof_n = 0;
+	return LA_OK;
+}
+
+int la_gpu_profile_read(la_gpu_ctx *c, float *ms, const char **names, int cap)
+{
+	if (!c || !ms) return LA_ERR_ARG;
+	if (!c->prof_on || c->prof_n == 0)
+		return 0;
+	HIPCHK(c, hipEventSynchronize(c->prof_ev[c->prof_n]));
+	int n = c->prof_n < cap ? c->prof_n : cap;
+	for (int i = 0; i < n; i++) {
+		HIPCHK(c, hipEventElapsedTime(&ms[i], c->prof_ev[i], c->prof_ev[i + 1]));
+		if (names) names[i] = c->prof_name[i];
+	}
+	return n;
+}
+
 /* ------------------------------------------------------------------ hashes */
 
 int la_gpu_xxh32_many(la_gpu_ctx *c, const uint8_t *d_base, const la_hash_job *d_jobs,
@@ -220,14 +266,20 @@ int la_gpu_lz4_decode(la_gpu_ctx *c, const la_lz4_batch *bt)
 	void *d_scan = ws + align_up((uint64_t)bt->n_blocks * sizeof(uint32_t), 256);
 	const bool verify = !(bt->options & LA_LZ4_OPT_NO_VERIFY);
 
+	prof_begin(c);
 	if (bt->n_blocks)
 		HIPCHK(c, hipMemsetAsync(bt->d_block_status, 0, (size_t)bt->n_blocks * sizeof(uint32_t), s));
-	if (verify)
+	if (verify) {
 		la_launch_lz4_block_sums(s, bt->d_src, bt->d_blocks, bt->n_blocks, bt->d_block_status);
+		prof_mark(c, "lz4_block_sums");
+	}
 	la_launch_lz4_measure(s, bt->d_src, bt->d_blocks, bt->n_blocks, bt->d_out_len, d_nseq, bt->d_block_status);
+	prof_mark(c, "lz4_measure");
 	la_launch_scan_u32(s, bt->d_out_len, bt->n_blocks, bt->d_dst_off, d_scan);
+	prof_mark(c, "scan");
 	la_launch_lz4_expand_general(s, bt->d_src, bt->src_bytes, bt->d_blocks, bt->n_blocks, bt->d_dst,
 	    bt->dst_cap, bt->d_dst_off, bt->d_out_len, bt->d_block_status);
+	prof_mark(c, "lz4_expand");
 	if (bt->n_frames) {
 		if (verify)
 			la_launch_lz4_frame_sums(s, bt->d_src, bt->d_dst, bt->d_frames, bt->n_frames,
@@ -235,9 +287,11 @@ int la_gpu_lz4_decode(la_gpu_ctx *c, const la_lz4_batch *bt)
 		else
 			HIPCHK(c, hipMemsetAsync(bt->d_frame_status, 0, (size_t)bt->n_frames * sizeof(uint32_t), s));
 	}
+	prof_mark(c, "lz4_frame_sums");
 	if (bt->d_summary)
 		la_launch_lz4_summary(s, bt->d_out_len, bt->d_block_status, bt->n_blocks,
 		    bt->d_frame_status, bt->n_frames, bt->d_dst_off, bt->d_summary);
+	prof_mark(c, "summary");
 	HIPCHK(c, hipGetLastError());
 	return LA_OK;
 }

@@ -89,6 +89,12 @@ int orc_lz4_block_decode(const uint8_t *src, int src_len,
 		if (op + length > oend - LASTLITERALS)
 			return -1;
 
+		if (offset >= length && offset <= op) {
+			/* no overlap, source entirely inside this block's output */
+			memcpy(dst + op, dst + op - offset, (size_t)length);
+			op += length;
+			continue;
+		}
 		/* byte-wise copy: overlapping matches replicate */
 		for (long i = 0; i < length; i++) {
 			long from = op - offset;
