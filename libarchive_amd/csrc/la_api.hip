@@ -235,13 +235,35 @@ int la_gpu_crc32_many(la_gpu_ctx *c, const uint8_t *d_base, const la_hash_job *d
 
 static uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) & ~(a - 1); }
 
+/* workspace layout of one lz4 batch */
+struct lz4_ws {
+	uint32_t *nseq;		/* [n] */
+	uint32_t *caps;		/* [n] table capacity per block */
+	uint64_t *table_off;	/* [n+1] */
+	void *scan;		/* scan scratch */
+	la_lz4_seq *table;
+	uint64_t table_cap;	/* entries */
+	uint64_t total;
+};
+
+static void lz4_ws_layout(lz4_ws *w, uint8_t *base, uint32_t n, uint64_t src_bytes, bool with_table)
+{
+	uint64_t o = 0;
+	w->nseq = (uint32_t *)(base + o); o += align_up((uint64_t)n * 4, 256);
+	w->caps = (uint32_t *)(base + o); o += align_up((uint64_t)n * 4, 256);
+	w->table_off = (uint64_t *)(base + o); o += align_up(((uint64_t)n + 1) * 8, 256);
+	w->scan = base + o; o += align_up(la_scan_scratch_bytes(n), 256);
+	/* a non-final sequence takes >= 3 payload bytes: sum(src_len/3 + 1) <= src_bytes/3 + n */
+	w->table_cap = with_table ? src_bytes / 3 + n : 0;
+	w->table = (la_lz4_seq *)(base + o); o += align_up(w->table_cap * sizeof(la_lz4_seq), 256);
+	w->total = o + 4096;
+}
+
 uint64_t la_gpu_lz4_workspace_bytes(uint32_t n_blocks, uint64_t src_bytes)
 {
-	(void)src_bytes;
-	uint64_t b = 0;
-	b += align_up((uint64_t)n_blocks * sizeof(uint32_t), 256);	/* nseq */
-	b += align_up(la_scan_scratch_bytes(n_blocks), 256);
-	return b + 4096;
+	lz4_ws w;
+	lz4_ws_layout(&w, NULL, n_blocks, src_bytes, true);
+	return w.total;
 }
 
 int la_gpu_lz4_decode(la_gpu_ctx *c, const la_lz4_batch *bt)
@@ -255,16 +277,16 @@ int la_gpu_lz4_decode(la_gpu_ctx *c, const la_lz4_batch *bt)
 		return LA_ERR_ARG;
 	if (!bt->d_dst_off)
 		return LA_ERR_ARG;
-	uint64_t need = la_gpu_lz4_workspace_bytes(bt->n_blocks, bt->src_bytes);
-	if (need > c->ws_bytes) {
-		int rc = la_gpu_reserve(c, need);
+	const bool fast = !(bt->options & LA_LZ4_OPT_GENERAL_ONLY);
+	const bool verify = !(bt->options & LA_LZ4_OPT_NO_VERIFY);
+	lz4_ws w;
+	lz4_ws_layout(&w, NULL, bt->n_blocks, bt->src_bytes, fast);
+	if (w.total > c->ws_bytes) {
+		int rc = la_gpu_reserve(c, w.total);
 		if (rc != LA_OK) return rc;
 	}
+	lz4_ws_layout(&w, (uint8_t *)c->ws, bt->n_blocks, bt->src_bytes, fast);
 	hipStream_t s = c->stream;
-	uint8_t *ws = (uint8_t *)c->ws;
-	uint32_t *d_nseq = (uint32_t *)ws;
-	void *d_scan = ws + align_up((uint64_t)bt->n_blocks * sizeof(uint32_t), 256);
-	const bool verify = !(bt->options & LA_LZ4_OPT_NO_VERIFY);
 
 	prof_begin(c);
 	if (bt->n_blocks)
@@ -273,13 +295,24 @@ int la_gpu_lz4_decode(la_gpu_ctx *c, const la_lz4_batch *bt)
 		la_launch_lz4_block_sums(s, bt->d_src, bt->d_blocks, bt->n_blocks, bt->d_block_status);
 		prof_mark(c, "lz4_block_sums");
 	}
-	la_launch_lz4_measure(s, bt->d_src, bt->d_blocks, bt->n_blocks, bt->d_out_len, d_nseq, bt->d_block_status);
-	prof_mark(c, "lz4_measure");
-	la_launch_scan_u32(s, bt->d_out_len, bt->n_blocks, bt->d_dst_off, d_scan);
+	if (fast) {
+		la_launch_lz4_table_caps(s, bt->d_blocks, bt->n_blocks, w.caps);
+		la_launch_scan_u32(s, w.caps, bt->n_blocks, w.table_off, w.scan);
+	}
+	la_launch_lz4_parse(s, bt->d_src, bt->src_bytes, bt->d_blocks, bt->n_blocks, bt->d_out_len, w.nseq,
+	    bt->d_block_status, fast ? w.table : NULL, w.table_off, w.table_cap);
+	prof_mark(c, "lz4_parse");
+	la_launch_scan_u32(s, bt->d_out_len, bt->n_blocks, bt->d_dst_off, w.scan);
 	prof_mark(c, "scan");
+	if (fast) {
+		la_launch_lz4_expand_fast(s, bt->d_src, bt->src_bytes, bt->d_blocks, bt->n_blocks, bt->d_dst,
+		    bt->dst_cap, bt->d_dst_off, bt->d_out_len, bt->d_block_status, w.nseq, w.table, w.table_off);
+		prof_mark(c, "lz4_expand");
+	}
 	la_launch_lz4_expand_general(s, bt->d_src, bt->src_bytes, bt->d_blocks, bt->n_blocks, bt->d_dst,
-	    bt->dst_cap, bt->d_dst_off, bt->d_out_len, bt->d_block_status);
-	prof_mark(c, "lz4_expand");
+	    bt->dst_cap, bt->d_dst_off, bt->d_out_len, bt->d_block_status, w.nseq,
+	    fast ? LA_LZ4_FAST_MAXSEQ : 0u);
+	prof_mark(c, fast ? "lz4_expand_general" : "lz4_expand");
 	if (bt->n_frames) {
 		if (verify)
 			la_launch_lz4_frame_sums(s, bt->d_src, bt->d_dst, bt->d_frames, bt->n_frames,

@@ -95,18 +95,36 @@ void la_launch_lz4_frame_sums(hipStream_t s, const uint8_t *d_src, const uint8_t
     const la_lz4_frame *d_frames, uint32_t n_frames, const uint64_t *d_dst_off,
     uint64_t dst_cap, uint32_t *d_frame_status);
 
-/* la_lz4.hip */
+/* la_lz4.hip, la_lz4_fast.hip */
 struct la_lz4_seq {	/* one LZ4 sequence, 8 bytes, written by the parse kernel */
 	uint16_t lit_src;	/* offset of the first literal inside the block payload */
 	uint16_t lit_len;
 	uint16_t dst;		/* output offset where the literals go */
-	uint16_t off;		/* match offset (0 in the final, literal-only sequence) */
+	uint16_t off;		/* match offset (0 in a final, literal-only sequence) */
 };
-void la_launch_lz4_measure(hipStream_t s, const uint8_t *d_src, const la_lz4_block *d_blocks,
-    uint32_t n, uint32_t *d_out_len, uint32_t *d_nseq, uint32_t *d_status);
+/* match length of sequence k = (k+1 < nseq ? seq[k+1].dst : out_len) - (dst + lit_len) */
+
+#define LA_LZ4_FAST_MAXSEQ 4096u	/* sequences per block the LDS-window kernel holds */
+
+/* blocks the LDS-window kernel may take: compressed, independent, window <= 64 KiB */
+__host__ __device__ __forceinline__ bool la_lz4_fast_eligible(const la_lz4_block &b)
+{
+	return !(b.flags & (LA_LZ4B_STORED | LA_LZ4B_DEPENDENT)) && b.dst_cap <= 65536u && b.src_len <= 65536u;
+}
+
+void la_launch_lz4_table_caps(hipStream_t s, const la_lz4_block *d_blocks, uint32_t n, uint32_t *d_caps);
+void la_launch_lz4_parse(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
+    const la_lz4_block *d_blocks, uint32_t n, uint32_t *d_out_len, uint32_t *d_nseq,
+    uint32_t *d_status, la_lz4_seq *d_table /* NULL: measure only */, const uint64_t *d_table_off,
+    uint64_t table_cap /* entries */);
 void la_launch_lz4_expand_general(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
     const la_lz4_block *d_blocks, uint32_t n, uint8_t *d_dst, uint64_t dst_cap,
-    const uint64_t *d_dst_off, const uint32_t *d_out_len, const uint32_t *d_status);
+    const uint64_t *d_dst_off, const uint32_t *d_out_len, const uint32_t *d_status,
+    const uint32_t *d_nseq, uint32_t fast_max_seq /* 0: take every block */);
+void la_launch_lz4_expand_fast(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
+    const la_lz4_block *d_blocks, uint32_t n, uint8_t *d_dst, uint64_t dst_cap,
+    const uint64_t *d_dst_off, const uint32_t *d_out_len, const uint32_t *d_status,
+    const uint32_t *d_nseq, const la_lz4_seq *d_table, const uint64_t *d_table_off);
 
 /* la_scan.hip */
 void la_launch_scan_u32(hipStream_t s, const uint32_t *d_in, uint32_t n, uint64_t *d_out /* n+1 */,

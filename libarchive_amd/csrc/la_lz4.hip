@@ -26,17 +26,54 @@
 #define LZ4_MFLIMIT 12
 #define LZ4_LASTLIT 5
 
-/* ------------------------------------------------------------------ measure */
+/* ------------------------------------------------------------------ parse */
 
 /*
+ * One LANE per block.  The token chain is a serial pointer chase, so the lane
+ * keeps an 8-byte window of the payload in registers: in the common case one
+ * (unaligned) 8-byte load per sequence feeds offset, match-length extension
+ * and the next token.  64 independent chains per wave hide the load latency.
+ *
  * Accept/reject rules = liblz4 1.9.3 safe decoder (see oracle/orc_lz4.c for
  * the derivation): exact input consumption, last-sequence rules relative to
  * the destination CAPACITY, match end margin, offset range, bounded length
  * extensions; offset 0 rejected.
+ *
+ * With EMIT the lane also writes the block's sequence table (8 bytes per
+ * sequence) for the LDS-window expand kernel.
  */
-__global__ __launch_bounds__(256) void lz4_measure_kernel(const uint8_t *__restrict__ src,
-    const la_lz4_block *__restrict__ blocks, uint32_t n, uint32_t *__restrict__ out_len,
-    uint32_t *__restrict__ nseq_out, uint32_t *__restrict__ status)
+struct byte_window {
+	const uint8_t *s;	/* payload */
+	uint64_t w;
+	int base;		/* payload offset of byte 0 of w */
+	int limit;		/* payload offsets >= limit lie outside the source image */
+};
+
+__device__ __forceinline__ uint32_t bw_get(byte_window &B, int p)
+{
+	uint32_t d = (uint32_t)(p - B.base);
+	if (d >= 8) {
+		if (p + 8 <= B.limit) {
+			__builtin_memcpy(&B.w, B.s + p, 8);
+		} else {
+			/* tail of the image: never read past it */
+			uint64_t v = 0;
+			for (int k = 0; k < 8; k++)
+				if (p + k < B.limit)
+					v |= (uint64_t)B.s[p + k] << (8 * k);
+			B.w = v;
+		}
+		B.base = p;
+		d = 0;
+	}
+	return (uint32_t)(B.w >> (8 * d)) & 0xffu;
+}
+
+template <bool EMIT>
+__global__ __launch_bounds__(256) void lz4_parse_kernel(const uint8_t *__restrict__ src,
+    uint64_t src_bytes, const la_lz4_block *__restrict__ blocks, uint32_t n,
+    uint32_t *__restrict__ out_len, uint32_t *__restrict__ nseq_out, uint32_t *__restrict__ status,
+    la_lz4_seq *__restrict__ table, const uint64_t *__restrict__ table_off, uint64_t table_cap)
 {
 	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n)
@@ -44,51 +81,65 @@ __global__ __launch_bounds__(256) void lz4_measure_kernel(const uint8_t *__restr
 	la_lz4_block b = blocks[i];
 	if (status[i] != LA_ST_OK) {	/* block checksum already failed */
 		out_len[i] = 0;
-		if (nseq_out) nseq_out[i] = 0;
+		nseq_out[i] = 0;
 		return;
 	}
 	if (b.flags & LA_LZ4B_STORED) {
 		out_len[i] = b.src_len;
-		if (nseq_out) nseq_out[i] = 0;
+		nseq_out[i] = 0;
 		return;
 	}
-	const uint8_t *s = src + b.src_off;
+	byte_window B;
+	B.s = src + b.src_off;
+	B.base = -64;
+	B.w = 0;
+	int64_t room = (int64_t)src_bytes - (int64_t)b.src_off;
+	B.limit = room < 0 ? 0 : (room > 0x7fffffff ? 0x7fffffff : (int)room);
 	const int iend = (int)b.src_len;
 	const int oend = (int)b.dst_cap;
 	const int dict = (b.flags & LA_LZ4B_DEPENDENT) ? 65536 : 0;	/* lz4.c:563-584: any offset reaches the zero-filled prefix */
+	/* emit only into a slot that lies inside the workspace (tables come from the host) */
+	const bool eligible = EMIT && la_lz4_fast_eligible(b);
+	const bool emit = eligible && table_off[i + 1] <= table_cap;
+	la_lz4_seq *tab = emit ? table + table_off[i] : nullptr;
 	int ip = 0, op = 0;
 	uint32_t nseq = 0;
 	bool ok = iend > 0;
 
 	while (ok) {
-		uint32_t token = s[ip++];
+		uint32_t token = bw_get(B, ip++);
 		int length = (int)(token >> 4);
 		if (length == 15) {
 			if (ip >= iend - 15) { ok = false; break; }
 			uint32_t x;
 			do {
-				x = s[ip++];
+				x = bw_get(B, ip++);
 				length += (int)x;
 				if (ip >= iend - 15)
 					break;
 			} while (x == 255);
 		}
-		nseq++;
 		if (op + length > oend - LZ4_MFLIMIT || ip + length > iend - (2 + 1 + LZ4_LASTLIT)) {
 			if (ip + length != iend || op + length > oend)
 				ok = false;
+			else if (emit && length > 0) {
+				la_lz4_seq e = { (uint16_t)ip, (uint16_t)length, (uint16_t)op, 0 };
+				tab[nseq] = e;
+				nseq++;
+			}
 			op += length;
 			break;
 		}
+		const int lit_src = ip, lit_len = length, lit_dst = op;
 		ip += length;
 		op += length;
-		int offset = (int)s[ip] | ((int)s[ip + 1] << 8);
+		int offset = (int)bw_get(B, ip) | ((int)bw_get(B, ip + 1) << 8);
 		ip += 2;
 		length = (int)(token & 15);
 		if (length == 15) {
 			uint32_t x;
 			do {
-				x = s[ip++];
+				x = bw_get(B, ip++);
 				length += (int)x;
 				if (ip >= iend - LZ4_LASTLIT + 1) { ok = false; break; }
 			} while (x == 255);
@@ -96,20 +147,48 @@ __global__ __launch_bounds__(256) void lz4_measure_kernel(const uint8_t *__restr
 		}
 		length += 4;
 		if (offset == 0 || offset > op + dict || op + length > oend - LZ4_LASTLIT) { ok = false; break; }
+		if (emit) {
+			la_lz4_seq e = { (uint16_t)lit_src, (uint16_t)lit_len, (uint16_t)lit_dst, (uint16_t)offset };
+			tab[nseq] = e;
+		}
+		nseq++;
 		op += length;
 	}
 	out_len[i] = ok ? (uint32_t)op : 0u;
-	if (nseq_out) nseq_out[i] = ok ? nseq : 0u;
+	/* an eligible block without a table slot must go to the general kernel */
+	nseq_out[i] = ok ? ((eligible && !emit) ? 0xFFFFFFFFu : nseq) : 0u;
 	if (!ok)
 		status[i] = LA_ST_LZ4_DECODE;
 }
 
-void la_launch_lz4_measure(hipStream_t s, const uint8_t *d_src, const la_lz4_block *d_blocks,
-    uint32_t n, uint32_t *d_out_len, uint32_t *d_nseq, uint32_t *d_status)
+/* table capacity per block: a non-final sequence takes at least 3 payload bytes */
+__global__ __launch_bounds__(256) void lz4_table_caps_kernel(const la_lz4_block *__restrict__ blocks,
+    uint32_t n, uint32_t *__restrict__ caps)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n)
+		return;
+	la_lz4_block b = blocks[i];
+	caps[i] = la_lz4_fast_eligible(b) ? b.src_len / 3 + 1 : 0u;
+}
+
+void la_launch_lz4_table_caps(hipStream_t s, const la_lz4_block *d_blocks, uint32_t n, uint32_t *d_caps)
 {
 	if (n == 0) return;
-	hipLaunchKernelGGL(lz4_measure_kernel, dim3((n + 255) / 256), dim3(256), 0, s,
-	    d_src, d_blocks, n, d_out_len, d_nseq, d_status);
+	hipLaunchKernelGGL(lz4_table_caps_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_blocks, n, d_caps);
+}
+
+void la_launch_lz4_parse(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
+    const la_lz4_block *d_blocks, uint32_t n, uint32_t *d_out_len, uint32_t *d_nseq,
+    uint32_t *d_status, la_lz4_seq *d_table, const uint64_t *d_table_off, uint64_t table_cap)
+{
+	if (n == 0) return;
+	if (d_table)
+		hipLaunchKernelGGL(lz4_parse_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, s,
+		    d_src, src_bytes, d_blocks, n, d_out_len, d_nseq, d_status, d_table, d_table_off, table_cap);
+	else
+		hipLaunchKernelGGL(lz4_parse_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, s,
+		    d_src, src_bytes, d_blocks, n, d_out_len, d_nseq, d_status, d_table, d_table_off, table_cap);
 }
 
 /* ------------------------------------------------------------------ general expand */
@@ -236,7 +315,7 @@ __device__ void lz4_expand_block_wave(const uint8_t *s, uint32_t src_len, const 
 __global__ __launch_bounds__(256) void lz4_expand_general_kernel(const uint8_t *__restrict__ src,
     uint64_t src_bytes, const la_lz4_block *__restrict__ blocks, uint32_t n, uint8_t *dst,
     uint64_t dst_cap, const uint64_t *__restrict__ dst_off, const uint32_t *__restrict__ out_len,
-    const uint32_t *__restrict__ status)
+    const uint32_t *__restrict__ status, const uint32_t *__restrict__ nseq, uint32_t fast_max_seq)
 {
 	int lane = threadIdx.x & 63;
 	uint32_t i = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
@@ -253,8 +332,10 @@ __global__ __launch_bounds__(256) void lz4_expand_general_kernel(const uint8_t *
 		la_lz4_block b = blocks[i];
 		uint8_t *d = dst + dst_off[i];
 		uint32_t olen = out_len[i];
-		/* never write past the slab, whatever the tables say */
-		if (status[i] == LA_ST_OK && olen > 0 && dst_off[i] + olen <= dst_cap) {
+		/* never write past the slab, whatever the tables say; blocks the LDS-window
+		 * kernel takes are skipped here (same predicate on both sides) */
+		if (status[i] == LA_ST_OK && olen > 0 && dst_off[i] + olen <= dst_cap &&
+		    !(fast_max_seq && la_lz4_fast_eligible(b) && nseq[i] <= fast_max_seq)) {
 			const uint8_t *s = src + b.src_off;
 			if (b.flags & LA_LZ4B_STORED) {
 				for (uint32_t j = (uint32_t)lane; j < b.src_len; j += LA_WAVE)
@@ -282,9 +363,10 @@ __global__ __launch_bounds__(256) void lz4_expand_general_kernel(const uint8_t *
 
 void la_launch_lz4_expand_general(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
     const la_lz4_block *d_blocks, uint32_t n, uint8_t *d_dst, uint64_t dst_cap,
-    const uint64_t *d_dst_off, const uint32_t *d_out_len, const uint32_t *d_status)
+    const uint64_t *d_dst_off, const uint32_t *d_out_len, const uint32_t *d_status,
+    const uint32_t *d_nseq, uint32_t fast_max_seq)
 {
 	if (n == 0) return;
 	hipLaunchKernelGGL(lz4_expand_general_kernel, dim3((n + 3) / 4), dim3(256), 0, s,
-	    d_src, src_bytes, d_blocks, n, d_dst, dst_cap, d_dst_off, d_out_len, d_status);
+	    d_src, src_bytes, d_blocks, n, d_dst, dst_cap, d_dst_off, d_out_len, d_status, d_nseq, fast_max_seq);
 }

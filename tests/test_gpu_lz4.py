@@ -16,10 +16,17 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_f
 MANIFEST = [e for e in json.load(open(os.path.join(GOLD, "manifest.json"))) if e["codec"] == "lz4"]
 
 
-def gpu_decode(ctx, image, options=0):
+def gpu_decode(ctx, image, options=None):
+    """Runs BOTH expand paths (LDS-window kernel + general kernel, and general kernel only)
+    and insists that they agree before returning the result."""
     from libarchive_amd.lz4 import decode_image
-    out, rc, msg, plan = decode_image(ctx, image, options=options)
-    return out.tobytes(), rc, msg
+    from libarchive_amd import _native as N
+    res = []
+    for opt in ((0, N.LA_LZ4_OPT_GENERAL_ONLY) if options is None else (options,)):
+        out, rc, msg, plan = decode_image(ctx, image, options=opt)
+        res.append((out.tobytes(), rc, msg))
+    assert all(r == res[0] for r in res), "fast and general expand kernels disagree"
+    return res[0]
 
 
 def test_library_is_loaded_and_device_present(gpu_ctx):
@@ -78,6 +85,52 @@ def test_real_compressor_blocks_and_overlaps(gpu_ctx):
     img, plain = S.lz4_frame(blocks, flg=0x74)
     out, rc, msg = gpu_decode(gpu_ctx, img)
     assert (rc, msg) == (0, "") and out == plain
+
+
+def test_many_short_sequences_route_to_general_kernel(gpu_ctx):
+    """> 4096 sequences in one 64 KiB block: beyond the LDS-window kernel's table."""
+    rnd = random.Random(4)
+    seqs = bytearray()
+    plain = bytearray()
+    while len(plain) < 65536 - 64:
+        lit = rnd.randbytes(1)
+        off = rnd.randint(1, min(len(plain) + 1, 65535))
+        seqs += bytes([0x10]) + lit + off.to_bytes(2, "little")      # 1 literal + 4-byte match
+        plain += lit
+        for _ in range(4):
+            plain.append(plain[-off])
+    fin = rnd.randbytes(65536 - len(plain))
+    seqs += bytes([0xF0]) + bytes([len(fin) - 15]) + fin if len(fin) >= 15 else bytes([len(fin) << 4]) + fin
+    plain += fin
+    img, pl = S.lz4_frame([(bytes(plain), S.lz4_block(bytes(seqs), bsum=True))] * 3, flg=0x74)
+    ref, res = O.lz4_stream_decode(img, 1 << 20)
+    assert res.rc == 0 and ref.tobytes() == pl
+    assert gpu_decode(gpu_ctx, img) == (pl, 0, "")
+
+
+def test_long_matches_and_chains(gpu_ctx):
+    """Long matches spanning many sequences, chained back-references and period-k overlaps."""
+    rnd = random.Random(12)
+    blocks = []
+    for k in range(12):
+        base = rnd.randbytes(rnd.randint(40, 300))
+        d = bytearray(base)
+        while len(d) < 60000:
+            mode = rnd.random()
+            if mode < 0.4:
+                o = rnd.randint(1, len(d)); n = rnd.randint(4, 2000)
+                for _ in range(n):
+                    d.append(d[-o])
+            elif mode < 0.7:
+                o = rnd.randint(1, 7); n = rnd.randint(4, 500)
+                for _ in range(n):
+                    d.append(d[-o])
+            else:
+                d += rnd.randbytes(rnd.randint(1, 60))
+        d = bytes(d[:rnd.randint(30000, 65536)])
+        blocks.append((d, S.lz4_block(S.lz4_compress_block(d), bsum=True)))
+    img, plain = S.lz4_frame(blocks, flg=0x74)
+    assert gpu_decode(gpu_ctx, img) == (plain, 0, "")
 
 
 def test_dependent_blocks(gpu_ctx):
