@@ -239,10 +239,14 @@ static uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) & ~(a - 1)
 struct lz4_ws {
 	uint32_t *nseq;		/* [n] */
 	uint32_t *caps;		/* [n] table capacity per block */
+	uint32_t *lcaps;	/* [n] literal-index capacity per block */
 	uint64_t *table_off;	/* [n+1] */
+	uint64_t *lidx_off;	/* [n+1] */
 	void *scan;		/* scan scratch */
 	la_lz4_seq *table;
 	uint64_t table_cap;	/* entries */
+	uint16_t *lidx;
+	uint64_t lidx_cap;	/* entries */
 	uint64_t total;
 };
 
@@ -251,11 +255,16 @@ static void lz4_ws_layout(lz4_ws *w, uint8_t *base, uint32_t n, uint64_t src_byt
 	uint64_t o = 0;
 	w->nseq = (uint32_t *)(base + o); o += align_up((uint64_t)n * 4, 256);
 	w->caps = (uint32_t *)(base + o); o += align_up((uint64_t)n * 4, 256);
+	w->lcaps = (uint32_t *)(base + o); o += align_up((uint64_t)n * 4, 256);
 	w->table_off = (uint64_t *)(base + o); o += align_up(((uint64_t)n + 1) * 8, 256);
+	w->lidx_off = (uint64_t *)(base + o); o += align_up(((uint64_t)n + 1) * 8, 256);
 	w->scan = base + o; o += align_up(la_scan_scratch_bytes(n), 256);
 	/* a non-final sequence takes >= 3 payload bytes: sum(src_len/3 + 1) <= src_bytes/3 + n */
 	w->table_cap = with_table ? src_bytes / 3 + n : 0;
 	w->table = (la_lz4_seq *)(base + o); o += align_up(w->table_cap * sizeof(la_lz4_seq), 256);
+	/* one u16 per 16 payload bytes: sum((src_len+15)/16) <= src_bytes/16 + n */
+	w->lidx_cap = with_table ? src_bytes / 16 + n : 0;
+	w->lidx = (uint16_t *)(base + o); o += align_up(w->lidx_cap * sizeof(uint16_t), 256);
 	w->total = o + 4096;
 }
 
@@ -296,17 +305,19 @@ int la_gpu_lz4_decode(la_gpu_ctx *c, const la_lz4_batch *bt)
 		prof_mark(c, "lz4_block_sums");
 	}
 	if (fast) {
-		la_launch_lz4_table_caps(s, bt->d_blocks, bt->n_blocks, w.caps);
+		la_launch_lz4_table_caps(s, bt->d_blocks, bt->n_blocks, w.caps, w.lcaps);
 		la_launch_scan_u32(s, w.caps, bt->n_blocks, w.table_off, w.scan);
+		la_launch_scan_u32(s, w.lcaps, bt->n_blocks, w.lidx_off, w.scan);
 	}
 	la_launch_lz4_parse(s, bt->d_src, bt->src_bytes, bt->d_blocks, bt->n_blocks, bt->d_out_len, w.nseq,
-	    bt->d_block_status, fast ? w.table : NULL, w.table_off, w.table_cap);
+	    bt->d_block_status, fast ? w.table : NULL, w.table_off, w.table_cap, w.lidx, w.lidx_off, w.lidx_cap);
 	prof_mark(c, "lz4_parse");
 	la_launch_scan_u32(s, bt->d_out_len, bt->n_blocks, bt->d_dst_off, w.scan);
 	prof_mark(c, "scan");
 	if (fast) {
 		la_launch_lz4_expand_fast(s, bt->d_src, bt->src_bytes, bt->d_blocks, bt->n_blocks, bt->d_dst,
-		    bt->dst_cap, bt->d_dst_off, bt->d_out_len, bt->d_block_status, w.nseq, w.table, w.table_off);
+		    bt->dst_cap, bt->d_dst_off, bt->d_out_len, bt->d_block_status, w.nseq, w.table, w.table_off,
+		    w.lidx, w.lidx_off);
 		prof_mark(c, "lz4_expand");
 	}
 	la_launch_lz4_expand_general(s, bt->d_src, bt->src_bytes, bt->d_blocks, bt->n_blocks, bt->d_dst,

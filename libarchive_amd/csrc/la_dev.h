@@ -50,23 +50,74 @@ __device__ __forceinline__ uint32_t xxh_avalanche(uint32_t h)
 	h ^= h >> 16;
 	return h;
 }
-/* one whole hash computed by ONE lane (many-hash kernels run one hash per lane) */
+/* one whole hash computed by ONE lane (many-hash kernels run one hash per lane).
+ * The stripe loop is unrolled four times so that a lane keeps 64 bytes of loads
+ * in flight: per-lane streams are latency bound, not issue bound. */
 __device__ __forceinline__ uint32_t xxh32_lane(const uint8_t *p, uint32_t len, uint32_t seed)
 {
 	const uint8_t *end = p + len;
 	uint32_t h;
 	if (len >= 16) {
 		uint32_t v1 = seed + XXH_P1 + XXH_P2, v2 = seed + XXH_P2, v3 = seed, v4 = seed - XXH_P1;
-		const uint8_t *limit = end - 16;
-		do {
+		while (p + 64 <= end) {
+			uint4 a = ld_u128(p), b = ld_u128(p + 16), c = ld_u128(p + 32), d = ld_u128(p + 48);
+			v1 = xxh_round(v1, a.x); v2 = xxh_round(v2, a.y); v3 = xxh_round(v3, a.z); v4 = xxh_round(v4, a.w);
+			v1 = xxh_round(v1, b.x); v2 = xxh_round(v2, b.y); v3 = xxh_round(v3, b.z); v4 = xxh_round(v4, b.w);
+			v1 = xxh_round(v1, c.x); v2 = xxh_round(v2, c.y); v3 = xxh_round(v3, c.z); v4 = xxh_round(v4, c.w);
+			v1 = xxh_round(v1, d.x); v2 = xxh_round(v2, d.y); v3 = xxh_round(v3, d.z); v4 = xxh_round(v4, d.w);
+			p += 64;
+		}
+		while (p + 16 <= end) {
 			uint4 x = ld_u128(p);
 			v1 = xxh_round(v1, x.x);
 			v2 = xxh_round(v2, x.y);
 			v3 = xxh_round(v3, x.z);
 			v4 = xxh_round(v4, x.w);
 			p += 16;
-		} while (p <= limit);
+		}
 		h = rotl32(v1, 1) + rotl32(v2, 7) + rotl32(v3, 12) + rotl32(v4, 18);
+	} else {
+		h = seed + XXH_P5;
+	}
+	h += len;
+	while (p + 4 <= end) {
+		h = rotl32(h + ld_u32(p) * XXH_P3, 17) * XXH_P4;
+		p += 4;
+	}
+	while (p < end) {
+		h = rotl32(h + (uint32_t)(*p) * XXH_P5, 11) * XXH_P1;
+		p++;
+	}
+	return xxh_avalanche(h);
+}
+
+/* one hash computed by FOUR adjacent lanes (lane j of the quad owns accumulator
+ * v(j+1) and reads the j-th dword of every 16-byte stripe, so a quad's load is one
+ * contiguous 16 bytes).  Used for the long content-checksum chains, where there
+ * are few hashes and each is long.  Result valid in all four lanes. */
+__device__ __forceinline__ uint32_t xxh32_quad(const uint8_t *p, uint32_t len, uint32_t seed, int j)
+{
+	const uint8_t *end = p + len;
+	uint32_t h;
+	if (len >= 16) {
+		uint32_t v = (j == 0) ? seed + XXH_P1 + XXH_P2 : (j == 1) ? seed + XXH_P2 : (j == 2) ? seed : seed - XXH_P1;
+		const uint8_t *q = p + 4 * j;
+		while (p + 128 <= end) {
+			uint32_t x0 = ld_u32(q), x1 = ld_u32(q + 16), x2 = ld_u32(q + 32), x3 = ld_u32(q + 48);
+			uint32_t x4 = ld_u32(q + 64), x5 = ld_u32(q + 80), x6 = ld_u32(q + 96), x7 = ld_u32(q + 112);
+			v = xxh_round(v, x0); v = xxh_round(v, x1); v = xxh_round(v, x2); v = xxh_round(v, x3);
+			v = xxh_round(v, x4); v = xxh_round(v, x5); v = xxh_round(v, x6); v = xxh_round(v, x7);
+			p += 128; q += 128;
+		}
+		while (p + 16 <= end) {
+			v = xxh_round(v, ld_u32(q));
+			p += 16; q += 16;
+		}
+		const int rot = (j == 0) ? 1 : (j == 1) ? 7 : (j == 2) ? 12 : 18;
+		uint32_t t = rotl32(v, rot);
+		t += __shfl_xor(t, 1, 64);
+		t += __shfl_xor(t, 2, 64);
+		h = t;
 	} else {
 		h = seed + XXH_P5;
 	}
@@ -112,11 +163,12 @@ __host__ __device__ __forceinline__ bool la_lz4_fast_eligible(const la_lz4_block
 	return !(b.flags & (LA_LZ4B_STORED | LA_LZ4B_DEPENDENT)) && b.dst_cap <= 65536u && b.src_len <= 65536u;
 }
 
-void la_launch_lz4_table_caps(hipStream_t s, const la_lz4_block *d_blocks, uint32_t n, uint32_t *d_caps);
+void la_launch_lz4_table_caps(hipStream_t s, const la_lz4_block *d_blocks, uint32_t n, uint32_t *d_caps,
+    uint32_t *d_lcaps);
 void la_launch_lz4_parse(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
     const la_lz4_block *d_blocks, uint32_t n, uint32_t *d_out_len, uint32_t *d_nseq,
     uint32_t *d_status, la_lz4_seq *d_table /* NULL: measure only */, const uint64_t *d_table_off,
-    uint64_t table_cap /* entries */);
+    uint64_t table_cap /* entries */, uint16_t *d_lidx, const uint64_t *d_lidx_off, uint64_t lidx_cap);
 void la_launch_lz4_expand_general(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
     const la_lz4_block *d_blocks, uint32_t n, uint8_t *d_dst, uint64_t dst_cap,
     const uint64_t *d_dst_off, const uint32_t *d_out_len, const uint32_t *d_status,
@@ -124,7 +176,8 @@ void la_launch_lz4_expand_general(hipStream_t s, const uint8_t *d_src, uint64_t 
 void la_launch_lz4_expand_fast(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
     const la_lz4_block *d_blocks, uint32_t n, uint8_t *d_dst, uint64_t dst_cap,
     const uint64_t *d_dst_off, const uint32_t *d_out_len, const uint32_t *d_status,
-    const uint32_t *d_nseq, const la_lz4_seq *d_table, const uint64_t *d_table_off);
+    const uint32_t *d_nseq, const la_lz4_seq *d_table, const uint64_t *d_table_off,
+    const uint16_t *d_lidx, const uint64_t *d_lidx_off);
 
 /* la_scan.hip */
 void la_launch_scan_u32(hipStream_t s, const uint32_t *d_in, uint32_t n, uint64_t *d_out /* n+1 */,

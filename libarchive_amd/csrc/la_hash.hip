@@ -44,31 +44,35 @@ __global__ __launch_bounds__(256) void lz4_block_sums_kernel(const uint8_t *__re
 }
 
 /* per frame: descriptor check byte (lz4.c:446-451) and content checksum over the
- * frame's decoded bytes (lz4.c:639-665) */
+ * frame's decoded bytes (lz4.c:639-665).  Four lanes per frame (xxh32_quad): frames
+ * are few and their chains long. */
 __global__ __launch_bounds__(64) void lz4_frame_sums_kernel(const uint8_t *__restrict__ src,
     const uint8_t *__restrict__ dst, const la_lz4_frame *__restrict__ frames, uint32_t n,
     const uint64_t *__restrict__ dst_off, uint64_t dst_cap, uint32_t *__restrict__ fstatus)
 {
-	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t i = t >> 2;
+	int j = (int)(t & 3);
 	if (i >= n)
-		return;
+		return;		/* n is rounded so that whole quads leave together */
 	la_lz4_frame f = frames[i];
 	uint32_t st = LA_ST_OK;
 	if (f.flags & LA_LZ4F_HEADER_SUM) {
-		uint32_t h = xxh32_lane(src + f.desc_off, f.desc_len - 1, 0);
+		uint32_t h = xxh32_quad(src + f.desc_off, f.desc_len - 1, 0, j);
 		if (((h >> 8) & 0xff) != src[f.desc_off + f.desc_len - 1])
 			st = LA_ST_LZ4_BAD_HEADER_SUM;
 	}
 	if (st == LA_ST_OK && (f.flags & LA_LZ4F_CONTENT_SUM)) {
 		uint64_t a = dst_off[f.first_block], e = dst_off[f.first_block + f.n_blocks];
-		/* xxhash.c:234: the length is an unsigned int there */
 		if (e <= dst_cap) {
-			uint32_t h = xxh32_lane(dst + a, (uint32_t)(e - a), 0);
+			/* xxhash.c:234: the length is an unsigned int there */
+			uint32_t h = xxh32_quad(dst + a, (uint32_t)(e - a), 0, j);
 			if (h != f.content_sum)
 				st = LA_ST_LZ4_BAD_CONTENT_SUM;
 		}
 	}
-	fstatus[i] = st;
+	if (j == 0)
+		fstatus[i] = st;
 }
 
 void la_launch_xxh32_many(hipStream_t s, const uint8_t *d_base, const la_hash_job *d_jobs,
@@ -90,7 +94,7 @@ void la_launch_lz4_frame_sums(hipStream_t s, const uint8_t *d_src, const uint8_t
     uint32_t *d_frame_status)
 {
 	if (n_frames == 0) return;
-	hipLaunchKernelGGL(lz4_frame_sums_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, s,
+	hipLaunchKernelGGL(lz4_frame_sums_kernel, dim3((n_frames + 15) / 16), dim3(64), 0, s,
 	    d_src, d_dst, d_frames, n_frames, d_dst_off, dst_cap, d_frame_status);
 }
 

@@ -73,7 +73,8 @@ template <bool EMIT>
 __global__ __launch_bounds__(256) void lz4_parse_kernel(const uint8_t *__restrict__ src,
     uint64_t src_bytes, const la_lz4_block *__restrict__ blocks, uint32_t n,
     uint32_t *__restrict__ out_len, uint32_t *__restrict__ nseq_out, uint32_t *__restrict__ status,
-    la_lz4_seq *__restrict__ table, const uint64_t *__restrict__ table_off, uint64_t table_cap)
+    la_lz4_seq *__restrict__ table, const uint64_t *__restrict__ table_off, uint64_t table_cap,
+    uint16_t *__restrict__ lit_index, const uint64_t *__restrict__ lidx_off, uint64_t lidx_cap)
 {
 	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n)
@@ -100,8 +101,11 @@ __global__ __launch_bounds__(256) void lz4_parse_kernel(const uint8_t *__restric
 	const int dict = (b.flags & LA_LZ4B_DEPENDENT) ? 65536 : 0;	/* lz4.c:563-584: any offset reaches the zero-filled prefix */
 	/* emit only into a slot that lies inside the workspace (tables come from the host) */
 	const bool eligible = EMIT && la_lz4_fast_eligible(b);
-	const bool emit = eligible && table_off[i + 1] <= table_cap;
+	const bool emit = eligible && table_off[i + 1] <= table_cap && lidx_off[i + 1] <= lidx_cap;
 	la_lz4_seq *tab = emit ? table + table_off[i] : nullptr;
+	/* lidx[c] = first sequence that still has literal bytes at or after payload offset 16*c */
+	uint16_t *lidx = emit ? lit_index + lidx_off[i] : nullptr;
+	int nchunk = 0;
 	int ip = 0, op = 0;
 	uint32_t nseq = 0;
 	bool ok = iend > 0;
@@ -125,6 +129,8 @@ __global__ __launch_bounds__(256) void lz4_parse_kernel(const uint8_t *__restric
 			else if (emit && length > 0) {
 				la_lz4_seq e = { (uint16_t)ip, (uint16_t)length, (uint16_t)op, 0 };
 				tab[nseq] = e;
+				for (; 16 * nchunk < ip + length; nchunk++)
+					lidx[nchunk] = (uint16_t)nseq;
 				nseq++;
 			}
 			op += length;
@@ -150,10 +156,15 @@ __global__ __launch_bounds__(256) void lz4_parse_kernel(const uint8_t *__restric
 		if (emit) {
 			la_lz4_seq e = { (uint16_t)lit_src, (uint16_t)lit_len, (uint16_t)lit_dst, (uint16_t)offset };
 			tab[nseq] = e;
+			for (; 16 * nchunk < lit_src + lit_len; nchunk++)
+				lidx[nchunk] = (uint16_t)nseq;
 		}
 		nseq++;
 		op += length;
 	}
+	if (emit && ok)
+		for (; 16 * nchunk < iend; nchunk++)
+			lidx[nchunk] = (uint16_t)nseq;	/* no literals from here on */
 	out_len[i] = ok ? (uint32_t)op : 0u;
 	/* an eligible block without a table slot must go to the general kernel */
 	nseq_out[i] = ok ? ((eligible && !emit) ? 0xFFFFFFFFu : nseq) : 0u;
@@ -163,32 +174,37 @@ __global__ __launch_bounds__(256) void lz4_parse_kernel(const uint8_t *__restric
 
 /* table capacity per block: a non-final sequence takes at least 3 payload bytes */
 __global__ __launch_bounds__(256) void lz4_table_caps_kernel(const la_lz4_block *__restrict__ blocks,
-    uint32_t n, uint32_t *__restrict__ caps)
+    uint32_t n, uint32_t *__restrict__ caps, uint32_t *__restrict__ lcaps)
 {
 	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n)
 		return;
 	la_lz4_block b = blocks[i];
 	caps[i] = la_lz4_fast_eligible(b) ? b.src_len / 3 + 1 : 0u;
+	lcaps[i] = la_lz4_fast_eligible(b) ? (b.src_len + 15) / 16 : 0u;
 }
 
-void la_launch_lz4_table_caps(hipStream_t s, const la_lz4_block *d_blocks, uint32_t n, uint32_t *d_caps)
+void la_launch_lz4_table_caps(hipStream_t s, const la_lz4_block *d_blocks, uint32_t n, uint32_t *d_caps,
+    uint32_t *d_lcaps)
 {
 	if (n == 0) return;
-	hipLaunchKernelGGL(lz4_table_caps_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_blocks, n, d_caps);
+	hipLaunchKernelGGL(lz4_table_caps_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_blocks, n, d_caps, d_lcaps);
 }
 
 void la_launch_lz4_parse(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
     const la_lz4_block *d_blocks, uint32_t n, uint32_t *d_out_len, uint32_t *d_nseq,
-    uint32_t *d_status, la_lz4_seq *d_table, const uint64_t *d_table_off, uint64_t table_cap)
+    uint32_t *d_status, la_lz4_seq *d_table, const uint64_t *d_table_off, uint64_t table_cap,
+    uint16_t *d_lidx, const uint64_t *d_lidx_off, uint64_t lidx_cap)
 {
 	if (n == 0) return;
 	if (d_table)
 		hipLaunchKernelGGL(lz4_parse_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, s,
-		    d_src, src_bytes, d_blocks, n, d_out_len, d_nseq, d_status, d_table, d_table_off, table_cap);
+		    d_src, src_bytes, d_blocks, n, d_out_len, d_nseq, d_status, d_table, d_table_off, table_cap,
+		    d_lidx, d_lidx_off, lidx_cap);
 	else
 		hipLaunchKernelGGL(lz4_parse_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, s,
-		    d_src, src_bytes, d_blocks, n, d_out_len, d_nseq, d_status, d_table, d_table_off, table_cap);
+		    d_src, src_bytes, d_blocks, n, d_out_len, d_nseq, d_status, d_table, d_table_off, table_cap,
+		    d_lidx, d_lidx_off, lidx_cap);
 }
 
 /* ------------------------------------------------------------------ general expand */
