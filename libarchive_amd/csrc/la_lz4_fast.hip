@@ -37,15 +37,56 @@
 #define FAST_THREADS 512
 #define FAST_WAVES   (FAST_THREADS / 64)
 
+/* Diagnostic build only (make diag, -DLA_DIAG): per-workgroup phase stamps go to a
+ * buffer of their own; no output value depends on them. */
+#ifdef LA_DIAG
+__device__ unsigned long long *la_diag_stamps;
+#define STAMP(slot)                                                                       \
+	do {                                                                              \
+		if (threadIdx.x == 0 && la_diag_stamps)                                    \
+			la_diag_stamps[(size_t)blockIdx.x * 8 + (slot)] = __builtin_readcyclecounter(); \
+	} while (0)
+#else
+#define STAMP(slot) do { } while (0)
+#endif
+
+/* LDS accepts unaligned 2/4/8-byte accesses on gfx950 (the compiler emits
+ * ds_read_b64 / ds_write_b64 for these), so window copies move 8 bytes per
+ * instruction at any byte address. */
+__device__ __forceinline__ uint64_t lds_ld8(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+__device__ __forceinline__ void lds_st8(uint8_t *p, uint64_t v) { __builtin_memcpy(p, &v, 8); }
+__device__ __forceinline__ void lds_st4(uint8_t *p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
+__device__ __forceinline__ void lds_st2(uint8_t *p, uint16_t v) { __builtin_memcpy(p, &v, 2); }
+
+/* store the low n (< 8) bytes of v */
+__device__ __forceinline__ void lds_st_tail(uint8_t *p, uint64_t v, uint32_t n)
+{
+	if (n & 4) { lds_st4(p, (uint32_t)v); p += 4; v >>= 32; }
+	if (n & 2) { lds_st2(p, (uint16_t)v); p += 2; v >>= 16; }
+	if (n & 1) *p = (uint8_t)v;
+}
+
+/* load n (< 8) bytes without touching bytes past p+n */
+__device__ __forceinline__ uint64_t lds_ld_tail(const uint8_t *p, uint32_t n)
+{
+	uint64_t v = 0;
+	uint32_t sh = 0;
+	if (n & 4) { uint32_t t; __builtin_memcpy(&t, p, 4); v = t; p += 4; sh = 32; }
+	if (n & 2) { uint16_t t; __builtin_memcpy(&t, p, 2); v |= (uint64_t)t << sh; p += 2; sh += 16; }
+	if (n & 1) v |= (uint64_t)(*p) << sh;
+	return v;
+}
+
 template <uint32_t MAXSEQ>
-__global__ __launch_bounds__(FAST_THREADS) void lz4_expand_fast_kernel(
+__global__ __launch_bounds__(FAST_THREADS, 4) void lz4_expand_fast_kernel(
     const uint8_t *__restrict__ src, uint64_t src_bytes, const la_lz4_block *__restrict__ blocks,
     uint32_t n, uint8_t *__restrict__ dst, uint64_t dst_cap, const uint64_t *__restrict__ dst_off,
-    const uint32_t *__restrict__ out_len, const uint32_t *__restrict__ status,
+    const uint32_t *__restrict__ out_len, uint32_t *status_out,
     const uint32_t *__restrict__ nseq, const la_lz4_seq *__restrict__ table,
     const uint64_t *__restrict__ table_off, const uint16_t *__restrict__ lit_index,
     const uint64_t *__restrict__ lidx_off)
 {
+	const uint32_t *status = status_out;
 	__shared__ __attribute__((aligned(16))) uint8_t win[65536 + 16];
 	__shared__ uint16_t dstpos[MAXSEQ + 4];
 	__shared__ uint32_t donebits[MAXSEQ / 32];
@@ -62,6 +103,7 @@ __global__ __launch_bounds__(FAST_THREADS) void lz4_expand_fast_kernel(
 	    doff + olen > dst_cap)
 		return;
 
+	STAMP(0);
 	const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const la_lz4_seq *tab = table + table_off[bi];
 	const uint16_t *lidx = lit_index + lidx_off[bi];
@@ -71,88 +113,172 @@ __global__ __launch_bounds__(FAST_THREADS) void lz4_expand_fast_kernel(
 	uint8_t *W = win + ((uintptr_t)g_out & 15);	/* W[i] <-> g_out[i], congruent mod 16 */
 	volatile uint32_t *done_v = donebits;
 
-	for (uint32_t k = tid; k < ns; k += FAST_THREADS)
-		dstpos[k] = tab[k].dst;
+	/* This thread's sequences k = (r*8 + wave)*64 + lane, r = 0..MAXSTEPS-1: their table
+	 * entries are fetched once, up front, and stay in registers for both passes over
+	 * them (output positions -> LDS now, matches later). */
+	constexpr uint32_t MAXSTEPS = MAXSEQ / FAST_THREADS;
+	la_lz4_seq ent[MAXSTEPS];
+#pragma unroll
+	for (uint32_t r = 0; r < MAXSTEPS; r++) {
+		const uint32_t k = (r * FAST_WAVES + wave) * 64 + lane;
+		la_lz4_seq z = { 0, 0, 0, 0 };
+		ent[r] = k < ns ? tab[k] : z;
+	}
 	if (tid < MAXSEQ / 32)
 		donebits[tid] = 0;
 
-	/* ---- phase L: literals, one thread per 16-byte payload chunk ---- */
+	/* ---- phase L: literals, one thread per 16-byte payload chunk ----
+	 * Four chunks per thread are in flight at a time: their payload and index loads
+	 * are issued together, then their table entries, then the byte scatter. */
 	const uint32_t nchunks = (b.src_len + 15) >> 4;
-	for (uint32_t c = tid; c < nchunks; c += FAST_THREADS) {
-		const uint32_t c0 = c << 4, c1 = c0 + 16;
-		uint32_t k = lidx[c];
-		uint4 v;
-		if ((uint64_t)c1 <= s_room)
-			v = ld_u128(s + c0);
-		else {
-			uint32_t t[4] = { 0, 0, 0, 0 };
-			for (uint32_t i = 0; c0 + i < s_room && i < 16; i++)
-				t[i >> 2] |= (uint32_t)s[c0 + i] << (8 * (i & 3));
-			v = make_uint4(t[0], t[1], t[2], t[3]);
-		}
-		/* the first entries are fetched together: most chunks touch <= 3 sequences */
-		la_lz4_seq e0 = { 0, 0, 0, 0 }, e1 = e0, e2 = e0;
-		if (k < ns) e0 = tab[k];
-		if (k + 1 < ns) e1 = tab[k + 1];
-		if (k + 2 < ns) e2 = tab[k + 2];
-		for (uint32_t it = 0; k < ns; it++, k++) {
-			la_lz4_seq e = it == 0 ? e0 : it == 1 ? e1 : it == 2 ? e2 : tab[k];
-			const uint32_t ls = e.lit_src, le = ls + e.lit_len;
-			if (ls >= c1)
-				break;
-			const uint32_t lo = ls > c0 ? ls : c0, hi = le < c1 ? le : c1;
-			for (uint32_t p = lo; p < hi; p++) {
-				const uint32_t i = p - c0;
-				const uint32_t dw = (i >> 2) == 0 ? v.x : (i >> 2) == 1 ? v.y : (i >> 2) == 2 ? v.z : v.w;
-				W[e.dst + (p - ls)] = (uint8_t)(dw >> (8 * (i & 3)));
+	for (uint32_t base = 0; base < nchunks; base += 4 * FAST_THREADS) {
+		uint32_t kk[4];
+		uint4 vv[4];
+#pragma unroll
+		for (int u = 0; u < 4; u++) {
+			const uint32_t c = base + u * FAST_THREADS + tid;
+			kk[u] = 0xFFFFFFFFu;
+			vv[u] = make_uint4(0, 0, 0, 0);
+			if (c < nchunks) {
+				kk[u] = lidx[c];
+				const uint32_t c0 = c << 4;
+				if ((uint64_t)c0 + 16 <= s_room)
+					vv[u] = ld_u128(s + c0);
+				else {
+					/* last chunk of the image: never read past it */
+					uint64_t lo8 = 0, hi8 = 0;
+					for (uint32_t i = 0; c0 + i < s_room && i < 8; i++)
+						lo8 |= (uint64_t)s[c0 + i] << (8 * i);
+					for (uint32_t i = 8; c0 + i < s_room && i < 16; i++)
+						hi8 |= (uint64_t)s[c0 + i] << (8 * (i - 8));
+					vv[u] = make_uint4((uint32_t)lo8, (uint32_t)(lo8 >> 32), (uint32_t)hi8, (uint32_t)(hi8 >> 32));
+				}
 			}
-			if (le >= c1)
-				break;
+		}
+		la_lz4_seq pe[4][2];
+#pragma unroll
+		for (int u = 0; u < 4; u++) {
+#pragma unroll
+			for (int t = 0; t < 2; t++) {
+				la_lz4_seq z = { 0, 0, 0, 0 };
+				pe[u][t] = (kk[u] != 0xFFFFFFFFu && kk[u] + t < ns) ? tab[kk[u] + t] : z;
+			}
+		}
+#pragma unroll
+		for (int u = 0; u < 4; u++) {
+			if (kk[u] == 0xFFFFFFFFu)
+				continue;
+			const uint32_t c0 = (base + u * FAST_THREADS + tid) << 4, c1 = c0 + 16;
+			const uint4 v = vv[u];
+			uint32_t k = kk[u];
+			for (uint32_t it = 0; k < ns; it++, k++) {
+				la_lz4_seq e = it == 0 ? pe[u][0] : it == 1 ? pe[u][1] : tab[k];
+				const uint32_t ls = e.lit_src, le = ls + e.lit_len;
+				if (ls >= c1)
+					break;
+				const uint32_t lo = ls > c0 ? ls : c0, hi = le < c1 ? le : c1;
+				if (hi > lo) {
+					/* bytes [lo-c0, hi-c0) of the 16-byte register chunk -> window */
+					const uint32_t i = lo - c0, nb = hi - lo;
+					const uint64_t vlo = ((uint64_t)v.y << 32) | v.x, vhi = ((uint64_t)v.w << 32) | v.z;
+					uint64_t a, bq;	/* chunk shifted right by i bytes: a = low 8 bytes, bq = next 8 */
+					if (i >= 8) { a = vhi >> (8 * (i - 8)); bq = 0; }
+					else if (i == 0) { a = vlo; bq = vhi; }
+					else { a = (vlo >> (8 * i)) | (vhi << (64 - 8 * i)); bq = vhi >> (8 * i); }
+					uint8_t *wp = W + e.dst + (lo - ls);
+					if (nb >= 8) {
+						lds_st8(wp, a);
+						if (nb == 16) lds_st8(wp + 8, bq);
+						else lds_st_tail(wp + 8, bq, nb - 8);
+					} else
+						lds_st_tail(wp, a, nb);
+				}
+				if (le >= c1)
+					break;
+			}
 		}
 	}
-	__syncthreads();
-
-	/* ---- phase M: matches, one thread per sequence ---- */
-	const uint32_t nsteps = (ns + FAST_THREADS - 1) / FAST_THREADS;
-	for (uint32_t r = 0; r < nsteps; r++) {
+#pragma unroll
+	for (uint32_t r = 0; r < MAXSTEPS; r++) {
 		const uint32_t k = (r * FAST_WAVES + wave) * 64 + lane;
-		const bool active = k < ns;
-		la_lz4_seq e = { 0, 0, 0, 0 };
-		if (active)
-			e = tab[k];
-		const uint32_t d = e.dst, off = e.off;
-		const uint32_t mdst = d + e.lit_len;
-		uint32_t next = olen;
-		if (active && k + 1 < ns)
-			next = dstpos[k + 1];
-		const uint32_t mlen = active ? next - mdst : 0;
-		bool fin = mlen == 0;
-		if (active && fin)
-			atomicOr(&donebits[k >> 5], 1u << (k & 31));
+		if (k < ns)
+			dstpos[k] = ent[r].dst;
+	}
+	STAMP(1);
+	__syncthreads();
+	STAMP(2);
 
-		/* sequences [q, qend] produce the bytes this match reads (those before its own sequence) */
-		uint32_t q = 1, qend = 0;
+	/* ---- phase M: matches, one thread per sequence ----
+	 * First every step's dependency range [q, qend] (branch-free binary searches over
+	 * the output positions, interleaved across steps), then the steps in order. */
+	uint32_t qcur[MAXSTEPS];	/* search cursor, then (first dependency | count << 16) */
+#pragma unroll
+	for (uint32_t r = 0; r < MAXSTEPS; r++)
+		qcur[r] = 0;
+	for (uint32_t bit = MAXSEQ / 2; bit; bit >>= 1) {
+#pragma unroll
+		for (uint32_t r = 0; r < MAXSTEPS; r++) {
+			/* largest idx < k with dstpos[idx] <= s0 */
+			const uint32_t k = (r * FAST_WAVES + wave) * 64 + lane;
+			const uint32_t s0 = ent[r].dst + ent[r].lit_len - ent[r].off;
+			const uint32_t cand = qcur[r] + bit;
+			if (cand < k && k < ns && dstpos[cand] <= s0)
+				qcur[r] = cand;
+		}
+	}
+#pragma unroll
+	for (uint32_t r = 0; r < MAXSTEPS; r++) {
+		const uint32_t k = (r * FAST_WAVES + wave) * 64 + lane;
+		const uint32_t d = ent[r].dst, mdst = d + ent[r].lit_len, off = ent[r].off;
 		const uint32_t s0 = mdst - off;
-		if (!fin && s0 < d) {
+		uint32_t next = olen;
+		if (k + 1 < ns)
+			next = dstpos[k + 1];
+		const uint32_t mlen = k < ns ? next - mdst : 0;
+		uint32_t cnt = 0;	/* number of earlier sequences to wait for */
+		if (mlen != 0 && s0 < d) {
 			const uint32_t span = mlen < off ? mlen : off;
 			uint32_t hi_byte = s0 + span - 1;
 			if (hi_byte >= d)
 				hi_byte = d - 1;
-			uint32_t lo = 0, hi = k - 1;	/* largest index with dstpos[idx] <= s0 */
-			while (lo < hi) {
-				uint32_t mid = (lo + hi + 1) >> 1;
-				if (dstpos[mid] <= s0) lo = mid; else hi = mid - 1;
-			}
-			q = lo;
-			qend = lo;
-			while (qend + 1 < k && dstpos[qend + 1] <= hi_byte)
-				qend++;
+			uint32_t qe = qcur[r];
+			while (qe + 1 < k && dstpos[qe + 1] <= hi_byte)
+				qe++;
+			cnt = qe - qcur[r] + 1;
 		}
+		qcur[r] = (qcur[r] & 0xFFFFu) | (cnt << 16);
+	}
+
+#pragma unroll 1
+	for (uint32_t r = 0; r < MAXSTEPS; r++) {
+		if (r * FAST_THREADS >= ns)
+			break;
+		const uint32_t k = (r * FAST_WAVES + wave) * 64 + lane;
+		const bool active = k < ns;
+		/* registers of step r (the array is indexed by a loop counter: pick by selects) */
+		la_lz4_seq e = ent[0];
+		uint32_t qp = qcur[0];
+#pragma unroll
+		for (uint32_t t = 1; t < MAXSTEPS; t++)
+			if (r == t) { e = ent[t]; qp = qcur[t]; }
+		const uint32_t off = e.off;
+		const uint32_t mdst = e.dst + e.lit_len;
+		uint32_t next = olen;
+		if (active && k + 1 < ns)
+			next = dstpos[k + 1];
+		const uint32_t mlen = active ? next - mdst : 0;
+		const uint32_t s0 = mdst - off;
+		uint32_t q = qp & 0xFFFFu;
+		const uint32_t qstop = q + (qp >> 16);	/* exclusive; q == qstop: nothing to wait for */
+		uint32_t spins = 0;
+		bool fin = mlen == 0;
+		if (active && fin)
+			atomicOr(&donebits[k >> 5], 1u << (k & 31));
 
 		for (;;) {
 			if (!fin) {
 				/* advance q over finished sequences, a 32-bit word of flags at a time */
-				while (q <= qend) {
+				while (q < qstop) {
 					/* bit 0 of `word` is the flag of q; the zeros shifted in from the
 					 * top end the run at the word boundary */
 					uint32_t word = done_v[q >> 5] >> (q & 31);
@@ -162,20 +288,50 @@ __global__ __launch_bounds__(FAST_THREADS) void lz4_expand_fast_kernel(
 						break;
 					q += run;
 				}
-				if (q > qend) {
+				/* every wait is bounded: a dependency that never completes (impossible
+				 * for a table the parse kernel produced) fails the block instead of
+				 * hanging the GPU */
+				if (q < qstop && ++spins > (1u << 20)) {
+					status_out[bi] = LA_ST_LZ4_DECODE;
+					q = qstop;
+				}
+				if (q >= qstop) {
 					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 					uint8_t *mp = W + mdst;
 					const uint8_t *fp = W + s0;
 					if (off >= mlen) {
+						/* source and destination do not overlap: 8 bytes per LDS op,
+						 * the first 32 bytes fetched before anything is stored */
+						uint32_t i = 0;
+						if (mlen >= 32) {
+							for (; i + 32 <= mlen; i += 32) {
+								uint64_t a0 = lds_ld8(fp + i), a1 = lds_ld8(fp + i + 8);
+								uint64_t a2 = lds_ld8(fp + i + 16), a3 = lds_ld8(fp + i + 24);
+								lds_st8(mp + i, a0); lds_st8(mp + i + 8, a1);
+								lds_st8(mp + i + 16, a2); lds_st8(mp + i + 24, a3);
+							}
+						}
+						uint32_t rem = mlen - i;	/* < 32 */
+						uint64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+						if (rem >= 8) a0 = lds_ld8(fp + i); else a0 = lds_ld_tail(fp + i, rem);
+						if (rem >= 16) a1 = lds_ld8(fp + i + 8); else if (rem > 8) a1 = lds_ld_tail(fp + i + 8, rem - 8);
+						if (rem >= 24) a2 = lds_ld8(fp + i + 16); else if (rem > 16) a2 = lds_ld_tail(fp + i + 16, rem - 16);
+						if (rem > 24) a3 = lds_ld_tail(fp + i + 24, rem - 24);
+						if (rem >= 8) lds_st8(mp + i, a0); else lds_st_tail(mp + i, a0, rem);
+						if (rem >= 16) lds_st8(mp + i + 8, a1); else if (rem > 8) lds_st_tail(mp + i + 8, a1, rem - 8);
+						if (rem >= 24) lds_st8(mp + i + 16, a2); else if (rem > 16) lds_st_tail(mp + i + 16, a2, rem - 16);
+						if (rem > 24) lds_st_tail(mp + i + 24, a3, rem - 24);
+					} else if (off >= 8) {
+						/* overlapping, period >= 8: a forward 8-byte copy only reads bytes
+						 * that this thread stored at least one iteration earlier */
 						uint32_t i = 0;
 						for (; i + 8 <= mlen; i += 8) {
-							uint8_t a0 = fp[i], a1 = fp[i + 1], a2 = fp[i + 2], a3 = fp[i + 3];
-							uint8_t a4 = fp[i + 4], a5 = fp[i + 5], a6 = fp[i + 6], a7 = fp[i + 7];
-							mp[i] = a0; mp[i + 1] = a1; mp[i + 2] = a2; mp[i + 3] = a3;
-							mp[i + 4] = a4; mp[i + 5] = a5; mp[i + 6] = a6; mp[i + 7] = a7;
+							uint64_t a = lds_ld8(mp + i - off);
+							lds_st8(mp + i, a);
+							asm volatile("" ::: "memory");	/* keep load/store order: the ranges overlap */
 						}
 						for (; i < mlen; i++)
-							mp[i] = fp[i];
+							((volatile uint8_t *)mp)[i] = ((volatile uint8_t *)mp)[(int)i - (int)off];
 					} else {
 						/* overlapping match: replicate with period `off`; every byte
 						 * read is one this thread (or an earlier sequence) already wrote */
@@ -189,10 +345,12 @@ __global__ __launch_bounds__(FAST_THREADS) void lz4_expand_fast_kernel(
 			}
 			if (__ballot(!fin) == 0)
 				break;
-			__builtin_amdgcn_s_sleep(1);
+			__builtin_amdgcn_s_sleep(2);	/* back off: polling waves share the LDS with copying ones */
 		}
 	}
+	STAMP(3);
 	__syncthreads();
+	STAMP(4);
 
 	/* ---- phase F: window -> decoded slab, 16 bytes per lane per step ---- */
 	uint32_t head = (16u - (uint32_t)((uintptr_t)g_out & 15)) & 15u;
@@ -207,11 +365,20 @@ __global__ __launch_bounds__(FAST_THREADS) void lz4_expand_fast_kernel(
 	const uint32_t tail0 = head + (nflush << 4);
 	if (tail0 + tid < olen)
 		g_out[tail0 + tid] = W[tail0 + tid];
+	STAMP(5);
 }
+
+#ifdef LA_DIAG
+extern "C" int la_diag_set_stamps(void *d_buf)
+{
+	unsigned long long *p = (unsigned long long *)d_buf;
+	return (int)hipMemcpyToSymbol(HIP_SYMBOL(la_diag_stamps), &p, sizeof(p));
+}
+#endif
 
 void la_launch_lz4_expand_fast(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
     const la_lz4_block *d_blocks, uint32_t n, uint8_t *d_dst, uint64_t dst_cap,
-    const uint64_t *d_dst_off, const uint32_t *d_out_len, const uint32_t *d_status,
+    const uint64_t *d_dst_off, const uint32_t *d_out_len, uint32_t *d_status,
     const uint32_t *d_nseq, const la_lz4_seq *d_table, const uint64_t *d_table_off,
     const uint16_t *d_lidx, const uint64_t *d_lidx_off)
 {
