@@ -81,7 +81,9 @@ enum {
 	LA_ST_GZ_DATA             = 5,	/* gzip.c:494-499 -> "gzip decompression failed" */
 	LA_ST_GZ_TRUNCATED        = 6,	/* gzip.c:464-469 -> "truncated gzip input" */
 	LA_ST_GZ_BAD_CRC          = 7,	/* NEW (reference never checks, gzip.c:423) */
-	LA_ST_GZ_BAD_ISIZE        = 8	/* NEW */
+	LA_ST_GZ_BAD_ISIZE        = 8,	/* NEW */
+	LA_ST_GZ_OUT_FULL         = 9,	/* member produced more than dst_cap bytes: host retries with a larger slot */
+	LA_ST_GZ_NO_TRAILER       = 10	/* deflate body complete, fewer than 8 trailer bytes inside src_len (gzip.c:419-421) */
 };
 
 /* =====================================================================

@@ -52,6 +52,37 @@ void la_lz4_index_free(la_lz4_index *idx);
 /* Bid functions (lz4.c:138-183, gzip.c:244-255) over a peeked buffer */
 int  la_lz4_bid_bytes(const uint8_t *p, size_t avail);
 
+/* ---- gzip ---- */
+typedef struct la_gz_header {	/* what peek_at_header (gzip.c:128-239) extracts */
+	uint64_t off;		/* where the member starts in the image */
+	uint32_t len;		/* header bytes */
+	uint32_t mtime;
+	uint32_t name_off;	/* offset of the FNAME string inside the image, 0 if absent */
+	uint32_t bgzf_size;	/* total member size from a BGZF "BC" extra subfield, 0 if absent */
+} la_gz_header;
+
+typedef struct la_gz_index {
+	la_gz_member *members;	/* src_off/src_len = deflate body + trailer (+ slack when speculative) */
+	la_gz_header *headers;
+	uint32_t      n, cap;
+	int           end_kind;	/* LA_END_* : EOF (silent end / trailing garbage), TRUNCATED, NEED_MORE */
+	uint64_t      consumed;	/* bytes of the image covered by the indexed members */
+	uint64_t      max_out;	/* sum of dst_cap */
+	int           speculative;	/* 1: some boundaries come from the 1f 8b 08 scan and must be confirmed by the decode */
+} la_gz_index;
+
+/* Header length (0 = not a gzip header / not enough bytes), gzip.c:128-239 */
+size_t la_gz_header_parse(const uint8_t *p, size_t avail, la_gz_header *h);
+int    la_gz_bid_bytes(const uint8_t *p, size_t avail);
+/* Walk img[0..len): member table with per-member output slots (dst_off assigned back to
+ * back from each member's ISIZE claim).  first_only: index just the first member. */
+int    la_gz_index_build(const uint8_t *img, uint64_t len, int at_eof, la_gz_index *idx);
+/* first_skip: candidate boundaries to pass over for the first member (refuted by a decode);
+ * first_cap: minimum output slot of the first member (its ISIZE claim proved too small) */
+int    la_gz_index_build2(const uint8_t *img, uint64_t len, int at_eof, uint32_t first_skip,
+           uint32_t first_cap, la_gz_index *idx);
+void   la_gz_index_free(la_gz_index *idx);
+
 /* The reference's error string for a device status word / an end kind */
 const char *la_status_message(uint32_t la_st);
 const char *la_end_message(int end_kind, int is_gzip);

@@ -344,8 +344,21 @@ int la_gpu_gzip_decode(la_gpu_ctx *c, const la_gz_batch *bt)
 {
 	if (!c || !bt)
 		return LA_ERR_ARG;
-	snprintf(c->err, sizeof(c->err), "la_gpu_gzip_decode: deflate kernels not built into this library yet");
-	return LA_ERR_ARG;
+	if (bt->n_members && (!bt->d_src || !bt->d_members || !bt->d_dst || !bt->d_results))
+		return LA_ERR_ARG;
+	hipStream_t s = c->stream;
+	prof_begin(c);
+	la_launch_inflate(s, bt->d_src, bt->src_bytes, bt->d_members, bt->n_members, bt->d_dst, bt->dst_cap,
+	    bt->d_results);
+	prof_mark(c, "inflate");
+	la_launch_gz_verify(s, bt->d_src, bt->src_bytes, bt->d_members, bt->n_members, bt->d_dst,
+	    bt->d_results, !(bt->options & LA_GZ_OPT_NO_VERIFY));
+	prof_mark(c, "gz_crc32");
+	if (bt->d_summary)
+		la_launch_gz_summary(s, bt->d_results, bt->n_members, bt->d_summary);
+	prof_mark(c, "summary");
+	HIPCHK(c, hipGetLastError());
+	return LA_OK;
 }
 
 } /* extern "C" */

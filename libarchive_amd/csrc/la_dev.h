@@ -133,6 +133,78 @@ __device__ __forceinline__ uint32_t xxh32_quad(const uint8_t *p, uint32_t len, u
 	return xxh_avalanche(h);
 }
 
+/* 512-byte register window over the compressed payload: lane l holds the
+ * aligned dwords at base+4l (w0) and base+256+4l (w1). */
+struct src_window {
+	const uint8_t *base;	/* 4-byte aligned, wave-uniform */
+	const uint8_t *limit;	/* one past the last readable byte of the whole source image */
+	uint32_t w0, w1;
+};
+
+__device__ __forceinline__ uint32_t win_load(const src_window &W, const uint8_t *p)
+{
+	/* p is 4-aligned.  A dword that holds at least one byte of the image lies in
+	 * the same page as that byte, so loading it whole cannot fault; dwords
+	 * entirely past the image are never touched. */
+	return (p < W.limit) ? *(const uint32_t *)p : 0u;
+}
+
+__device__ __forceinline__ void win_reset(src_window &W, const uint8_t *q, int lane)
+{
+	W.base = (const uint8_t *)((uintptr_t)q & ~(uintptr_t)3);
+	W.w0 = win_load(W, W.base + 4 * lane);
+	W.w1 = win_load(W, W.base + 256 + 4 * lane);
+}
+
+/* byte at q (wave-uniform address, q >= W.base) */
+__device__ __forceinline__ uint32_t win_byte(src_window &W, const uint8_t *q, int lane)
+{
+	uint32_t d = (uint32_t)(q - W.base);
+	if (d >= 256) {
+		if (d < 512) {
+			W.base += 256;
+			W.w0 = W.w1;
+			W.w1 = win_load(W, W.base + 256 + 4 * lane);
+			d -= 256;
+		} else {
+			win_reset(W, q, lane);
+			d = (uint32_t)(q - W.base);
+		}
+	}
+	uint32_t dw = (uint32_t)__builtin_amdgcn_readlane((int)W.w0, (int)(d >> 2));
+	return (dw >> ((d & 3) * 8)) & 0xffu;
+}
+
+__device__ __forceinline__ void wave_mem_fence()
+{
+	/* make this wave's earlier global stores visible to its own later loads
+	 * (same CU, same L1): s_waitcnt vmcnt(0) is all the hardware needs */
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+/* unaligned little-endian dword at q (wave-uniform), served from the window */
+__device__ __forceinline__ uint32_t win_u32(src_window &W, const uint8_t *q, int lane)
+{
+	uint32_t d = (uint32_t)(q - W.base);
+	if (d + 4 > 256) {
+		if (d < 256) {
+			/* straddles the two halves: assemble from bytes (rare) */
+			uint32_t v = 0;
+			for (int k = 0; k < 4; k++)
+				v |= win_byte(W, q + k, lane) << (8 * k);
+			return v;
+		}
+		win_byte(W, q, lane);	/* slides or reloads the window */
+		d = (uint32_t)(q - W.base);
+	}
+	uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)W.w0, (int)(d >> 2));
+	uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)W.w0, (int)(((d >> 2) + 1) & 63));
+	if ((d >> 2) == 63)
+		hi = (uint32_t)__builtin_amdgcn_readlane((int)W.w1, 0);
+	return __builtin_amdgcn_alignbyte(hi, lo, d & 3);
+}
+
 /* ---- launch interface (definitions live next to their kernels) ---- */
 
 /* la_hash.hip */
@@ -178,6 +250,13 @@ void la_launch_lz4_expand_fast(hipStream_t s, const uint8_t *d_src, uint64_t src
     const uint64_t *d_dst_off, const uint32_t *d_out_len, uint32_t *d_status,
     const uint32_t *d_nseq, const la_lz4_seq *d_table, const uint64_t *d_table_off,
     const uint16_t *d_lidx, const uint64_t *d_lidx_off);
+
+/* la_inflate.hip */
+void la_launch_inflate(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
+    const la_gz_member *d_members, uint32_t n, uint8_t *d_dst, uint64_t dst_cap, la_gz_result *d_results);
+void la_launch_gz_verify(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
+    const la_gz_member *d_members, uint32_t n, const uint8_t *d_dst, la_gz_result *d_results, int verify);
+void la_launch_gz_summary(hipStream_t s, const la_gz_result *d_results, uint32_t n, la_batch_summary *d_summary);
 
 /* la_scan.hip */
 void la_launch_scan_u32(hipStream_t s, const uint32_t *d_in, uint32_t n, uint64_t *d_out /* n+1 */,

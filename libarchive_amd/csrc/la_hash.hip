@@ -235,3 +235,96 @@ void la_launch_crc32_many(hipStream_t s, const uint8_t *d_base, const la_hash_jo
 	if (blocks > 256 * 8) blocks = 256 * 8;
 	hipLaunchKernelGGL(crc32_many_kernel, dim3(blocks), dim3(256), 0, s, d_base, d_jobs, n, d_out);
 }
+
+/* ------------------------------------------------------------------ gzip trailer */
+
+/*
+ * One wave per member: CRC32 of the produced bytes (always reported), then the
+ * 8-byte trailer [crc32 LE][isize LE] that follows the deflate body.  The
+ * reference consumes the trailer without looking at it (gzip.c:423); a short
+ * trailer is its message-less ARCHIVE_FATAL (gzip.c:419-421).
+ */
+__global__ __launch_bounds__(256) void gz_verify_kernel(const uint8_t *__restrict__ src, uint64_t src_bytes,
+    const la_gz_member *__restrict__ members, uint32_t n, const uint8_t *__restrict__ dst,
+    la_gz_result *results, int verify)
+{
+	__shared__ uint32_t T[4 * 256];
+	crc_build_tables(T);
+	int lane = threadIdx.x & 63;
+	uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+	for (uint32_t i = wave; i < n; i += nwaves) {
+		la_gz_member m = members[i];
+		la_gz_result r = results[i];
+		if (r.status != LA_ST_OK)
+			continue;
+		uint32_t c = crc32_wave(T, dst + m.dst_off, r.out_len, 0, lane);
+		c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+		uint32_t st = LA_ST_OK;
+		uint64_t tr = m.src_off + r.consumed;
+		if ((uint64_t)r.consumed + 8 > m.src_len || tr + 8 > src_bytes)
+			st = LA_ST_GZ_NO_TRAILER;
+		else if (verify) {
+			if (ld_u32(src + tr) != c)
+				st = LA_ST_GZ_BAD_CRC;
+			else if (ld_u32(src + tr + 4) != r.out_len)
+				st = LA_ST_GZ_BAD_ISIZE;
+		}
+		if (lane == 0) {
+			results[i].crc32 = c;
+			results[i].status = st;
+		}
+	}
+}
+
+void la_launch_gz_verify(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
+    const la_gz_member *d_members, uint32_t n, const uint8_t *d_dst, la_gz_result *d_results, int verify)
+{
+	if (n == 0) return;
+	uint32_t blocks = (n + 3) / 4;
+	if (blocks > 256 * 8) blocks = 256 * 8;
+	hipLaunchKernelGGL(gz_verify_kernel, dim3(blocks), dim3(256), 0, s, d_src, src_bytes, d_members, n,
+	    d_dst, d_results, verify);
+}
+
+__global__ void gz_summary_init(la_batch_summary *sm)
+{
+	sm->total_out = 0; sm->n_bad_units = 0; sm->n_bad_frames = 0;
+	sm->first_bad_unit = 0xFFFFFFFFu; sm->first_bad_frame = 0xFFFFFFFFu;
+	sm->first_zero_unit = 0xFFFFFFFFu; sm->reserved = 0;
+}
+
+__global__ __launch_bounds__(256) void gz_summary_kernel(const la_gz_result *__restrict__ results, uint32_t n,
+    la_batch_summary *sm)
+{
+	uint32_t stride = gridDim.x * blockDim.x;
+	uint32_t bad = 0, first_bad = 0xFFFFFFFFu;
+	unsigned long long total = 0;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+		la_gz_result r = results[i];
+		total += r.out_len;
+		if (r.status != LA_ST_OK) {
+			bad++;
+			if (i < first_bad) first_bad = i;
+		}
+	}
+	for (int d = 32; d >= 1; d >>= 1) {
+		bad += __shfl_down(bad, d, 64);
+		total += __shfl_down(total, d, 64);
+		first_bad = min(first_bad, (uint32_t)__shfl_down(first_bad, d, 64));
+	}
+	if ((threadIdx.x & 63) == 0) {
+		if (bad) atomicAdd(&sm->n_bad_units, bad);
+		if (total) atomicAdd((unsigned long long *)&sm->total_out, total);
+		if (first_bad != 0xFFFFFFFFu) atomicMin(&sm->first_bad_unit, first_bad);
+	}
+}
+
+void la_launch_gz_summary(hipStream_t s, const la_gz_result *d_results, uint32_t n, la_batch_summary *d_summary)
+{
+	hipLaunchKernelGGL(gz_summary_init, dim3(1), dim3(1), 0, s, d_summary);
+	uint32_t blocks = (n + 255) / 256;
+	if (blocks == 0) blocks = 1;
+	if (blocks > 1024) blocks = 1024;
+	hipLaunchKernelGGL(gz_summary_kernel, dim3(blocks), dim3(256), 0, s, d_results, n, d_summary);
+}

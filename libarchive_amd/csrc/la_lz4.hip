@@ -209,56 +209,6 @@ void la_launch_lz4_parse(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes
 
 /* ------------------------------------------------------------------ general expand */
 
-/* 512-byte register window over the compressed payload: lane l holds the
- * aligned dwords at base+4l (w0) and base+256+4l (w1). */
-struct src_window {
-	const uint8_t *base;	/* 4-byte aligned, wave-uniform */
-	const uint8_t *limit;	/* one past the last readable byte of the whole source image */
-	uint32_t w0, w1;
-};
-
-__device__ __forceinline__ uint32_t win_load(const src_window &W, const uint8_t *p)
-{
-	/* p is 4-aligned.  A dword that holds at least one byte of the image lies in
-	 * the same page as that byte, so loading it whole cannot fault; dwords
-	 * entirely past the image are never touched. */
-	return (p < W.limit) ? *(const uint32_t *)p : 0u;
-}
-
-__device__ __forceinline__ void win_reset(src_window &W, const uint8_t *q, int lane)
-{
-	W.base = (const uint8_t *)((uintptr_t)q & ~(uintptr_t)3);
-	W.w0 = win_load(W, W.base + 4 * lane);
-	W.w1 = win_load(W, W.base + 256 + 4 * lane);
-}
-
-/* byte at q (wave-uniform address, q >= W.base) */
-__device__ __forceinline__ uint32_t win_byte(src_window &W, const uint8_t *q, int lane)
-{
-	uint32_t d = (uint32_t)(q - W.base);
-	if (d >= 256) {
-		if (d < 512) {
-			W.base += 256;
-			W.w0 = W.w1;
-			W.w1 = win_load(W, W.base + 256 + 4 * lane);
-			d -= 256;
-		} else {
-			win_reset(W, q, lane);
-			d = (uint32_t)(q - W.base);
-		}
-	}
-	uint32_t dw = (uint32_t)__builtin_amdgcn_readlane((int)W.w0, (int)(d >> 2));
-	return (dw >> ((d & 3) * 8)) & 0xffu;
-}
-
-__device__ __forceinline__ void wave_mem_fence()
-{
-	/* make this wave's earlier global stores visible to its own later loads
-	 * (same CU, same L1): s_waitcnt vmcnt(0) is all the hardware needs */
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
 /*
  * Decode one validated block with one wave.  d points at the block's slot in
  * the slab; bytes d[-dict_len..0) are the previous block (dependent frames),

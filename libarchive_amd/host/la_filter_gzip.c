@@ -1,0 +1,502 @@
+/*
+ * la_filter_gzip.c -- the gzip read filter with an MI355X data plane.
+ *
+ * Drop-in for libarchive/archive_read_support_filter_gzip.c: same public entry
+ * points (archive_read_support_filter_gzip and the deprecated
+ * archive_read_support_compression_gzip, gzip.c:85-117), same bidder
+ * (gzip.c:244-255), same filter name/code, same vtable shape
+ * {read, close, read_header} (gzip.c:298-305), same return codes and error
+ * strings.  read() gathers a window of the compressed stream, finds the
+ * member boundaries on the host (la_gzip_index.c), inflates all members of
+ * the window on the GPU (la_gpu_gzip_decode) and returns the decoded slab.
+ *
+ * Parity details kept on purpose:
+ *   - the trailer CRC32/ISIZE is computed on the device but, like the reference
+ *     (gzip.c:423), NOT enforced unless LA_GZIP_STRICT=1;
+ *   - on an error the reference has delivered whole 64 KiB output blocks only
+ *     (gzip.c:314, :446): this filter never hands out the last partial 64 KiB
+ *     of what it has decoded until the bytes after it are known to be fine, so
+ *     the bytes delivered before an error are exactly the reference's;
+ *   - entry name / mtime come from the last member header parsed while the
+ *     first 64 KiB were produced (gzip.c:160-163, :196-201, :280-296).
+ * There is no CPU decode path: without a usable GPU, init() fails the open.
+ *
+ * Environment: LA_GPU_DEVICE, LA_GPU_BATCH_MIB (as for lz4), LA_GZIP_STRICT.
+ */
+#include "la_read_private.h"
+#include "../../include/la_gpu.h"
+#include "../../include/la_host.h"
+#include <errno.h>
+#include <stdio.h>
+
+#define OUT_BLOCK 65536u	/* gzip.c:314 */
+
+struct gzip_private {
+	la_gpu_ctx *gpu;
+	uint8_t *stage;
+	size_t stage_cap, stage_len, batch_bytes;
+	int upstream_eof;
+	void *d_src, *d_dst, *d_tabs;
+	size_t d_src_cap, d_dst_cap, d_tabs_cap;
+	uint8_t *slab;		/* [carry | this batch's bytes] */
+	size_t slab_cap;
+	size_t carry_len;	/* decoded but not yet delivered (< 64 KiB) */
+	size_t last_ret;	/* bytes handed out by the previous read() */
+	la_gz_result *h_res;
+	size_t h_res_cap;
+	uint64_t total_out;	/* bytes decoded so far (delivered + carry) */
+	uint32_t hint_skip, hint_cap;
+	int strict;
+	/* header metadata (gzip.c:280-296) */
+	uint32_t mtime;
+	char *name;
+	int pending_fatal;
+	int pending_has_msg;
+	char pending_msg[128];
+	int eof;
+};
+
+static int gzip_bidder_bid(struct archive_read_filter_bidder *, struct archive_read_filter *);
+static int gzip_bidder_init(struct archive_read_filter *);
+static ssize_t gzip_filter_read(struct archive_read_filter *, const void **);
+static int gzip_filter_close(struct archive_read_filter *);
+static int gzip_read_header(struct archive_read_filter *, struct archive_entry *);
+
+static const struct archive_read_filter_bidder_vtable gzip_bidder_vtable = {
+	.bid = gzip_bidder_bid,
+	.init = gzip_bidder_init,
+};
+
+static const struct archive_read_filter_vtable gzip_reader_vtable = {
+	.read = gzip_filter_read,
+	.close = gzip_filter_close,
+	.read_header = gzip_read_header,
+};
+
+int archive_read_support_filter_gzip(struct archive *_a)
+{
+	struct archive_read *a = (struct archive_read *)_a;
+	if (__archive_read_register_bidder(a, NULL, "gzip", &gzip_bidder_vtable) != ARCHIVE_OK)
+		return ARCHIVE_FATAL;
+	return ARCHIVE_OK;
+}
+
+int archive_read_support_compression_gzip(struct archive *a)
+{
+	return archive_read_support_filter_gzip(a);
+}
+
+/*
+ * gzip.c:128-239 through the peek interface: the fixed 10 bytes first, then as
+ * much as the optional fields need (file names are limited to what upstream
+ * can expose in one peek, as in the reference).
+ */
+static int gzip_bidder_bid(struct archive_read_filter_bidder *self, struct archive_read_filter *filter)
+{
+	ssize_t avail;
+	(void)self;
+	const unsigned char *p = __archive_read_filter_ahead(filter, 10, &avail);
+	if (p == NULL || avail == 0)
+		return 0;
+	if (p[0] != 0x1f || p[1] != 0x8b || p[2] != 0x08 || (p[3] & 0xE0))
+		return 0;
+	/* optional fields: ask for more until the header parses or upstream runs dry */
+	size_t want = 10;
+	for (;;) {
+		size_t hl = la_gz_header_parse(p, (size_t)avail, NULL);
+		if (hl)
+			return 27;
+		if ((size_t)avail > want)
+			want = (size_t)avail;
+		want += 256;
+		p = __archive_read_filter_ahead(filter, want, &avail);
+		if (p == NULL)
+			return 0;
+	}
+}
+
+static int gz_gpu_fail(struct archive_read_filter *self, struct gzip_private *st, const char *what)
+{
+	archive_set_error(&self->archive->archive, ARCHIVE_ERRNO_MISC,
+	    "gzip GPU data plane: %s failed: %s", what, st->gpu ? la_gpu_last_error(st->gpu) : "no device");
+	return ARCHIVE_FATAL;
+}
+
+static int gzip_bidder_init(struct archive_read_filter *self)
+{
+	self->code = ARCHIVE_FILTER_GZIP;
+	self->name = "gzip";
+	struct gzip_private *st = calloc(1, sizeof(*st));
+	if (st == NULL) {
+		archive_set_error(&self->archive->archive, ENOMEM, "Can't allocate data for gzip decompression");
+		return ARCHIVE_FATAL;
+	}
+	const char *dev = getenv("LA_GPU_DEVICE"), *bm = getenv("LA_GPU_BATCH_MIB"), *sv = getenv("LA_GZIP_STRICT");
+	st->batch_bytes = (size_t)(bm && atoi(bm) > 0 ? atoi(bm) : 256) << 20;
+	st->strict = sv && atoi(sv) != 0;
+	int rc = la_gpu_open(dev ? atoi(dev) : 0, &st->gpu);
+	if (rc != LA_OK) {
+		archive_set_error(&self->archive->archive, ARCHIVE_ERRNO_MISC,
+		    "Can't initialize gzip GPU data plane (la_gpu_open: %d); no CPU fallback is built", rc);
+		free(st);
+		return ARCHIVE_FATAL;
+	}
+	self->data = st;
+	self->vtable = &gzip_reader_vtable;
+	return ARCHIVE_OK;
+}
+
+static int gzip_read_header(struct archive_read_filter *self, struct archive_entry *entry)
+{
+	struct gzip_private *st = (struct gzip_private *)self->data;
+	if (st->mtime != 0)	/* a mtime of 0 is considered invalid/missing */
+		archive_entry_set_mtime(entry, st->mtime, 0);
+	if (st->name)
+		archive_entry_set_pathname(entry, st->name);
+	return ARCHIVE_OK;
+}
+
+static int gz_grow_pinned(struct gzip_private *st, uint8_t **p, size_t *cap, size_t need, size_t keep)
+{
+	if (*cap >= need)
+		return 0;
+	size_t nc = *cap ? *cap : (1u << 20);
+	while (nc < need)
+		nc *= 2;
+	void *np = NULL;
+	if (la_gpu_malloc_host(st->gpu, &np, nc) != LA_OK)
+		return -1;
+	if (keep)
+		memcpy(np, *p, keep);
+	if (*p)
+		la_gpu_free_host(st->gpu, *p);
+	*p = np;
+	*cap = nc;
+	return 0;
+}
+
+static int gz_grow_dev(struct gzip_private *st, void **p, size_t *cap, size_t need)
+{
+	if (*cap >= need)
+		return 0;
+	size_t nc = *cap ? *cap : (1u << 20);
+	while (nc < need)
+		nc *= 2;
+	if (*p)
+		la_gpu_free(st->gpu, *p);
+	*p = NULL;
+	*cap = 0;
+	if (la_gpu_malloc(st->gpu, p, nc) != LA_OK)
+		return -1;
+	*cap = nc;
+	return 0;
+}
+
+#define ALIGN256(x) (((x) + 255) & ~(size_t)255)
+
+static void gz_set_fatal(struct gzip_private *st, const char *msg)
+{
+	st->pending_fatal = 1;
+	st->pending_has_msg = msg != NULL;
+	if (msg)
+		snprintf(st->pending_msg, sizeof(st->pending_msg), "%s", msg);
+}
+
+/*
+ * One batch: decode every indexed member, then walk the results in stream
+ * order.  On return *used = compressed bytes of the window that are done with,
+ * the slab holds carry + newly decoded bytes (st->carry_len updated to the
+ * total now waiting), *cutoff = stream offset up to which bytes may be
+ * delivered (everything, unless an error follows).
+ */
+static int gzip_run_batch(struct archive_read_filter *self, struct gzip_private *st,
+    const la_gz_index *x, size_t *used)
+{
+	const uint32_t n = x->n;
+	size_t o = 0;
+	const size_t o_mem = o; o += ALIGN256((size_t)n * sizeof(la_gz_member));
+	const size_t o_res = o; o += ALIGN256((size_t)n * sizeof(la_gz_result));
+	const size_t o_sum = o; o += 256;
+	size_t src_len = (size_t)x->consumed;
+	if (gz_grow_dev(st, &st->d_src, &st->d_src_cap, src_len + 64) < 0 ||
+	    gz_grow_dev(st, &st->d_dst, &st->d_dst_cap, (size_t)x->max_out + 64) < 0 ||
+	    gz_grow_dev(st, &st->d_tabs, &st->d_tabs_cap, o) < 0)
+		return gz_gpu_fail(self, st, "device allocation");
+	uint8_t *T = st->d_tabs;
+	if (la_gpu_memcpy_h2d(st->gpu, st->d_src, st->stage, src_len) != LA_OK ||
+	    la_gpu_memcpy_h2d(st->gpu, T + o_mem, x->members, (size_t)n * sizeof(la_gz_member)) != LA_OK)
+		return gz_gpu_fail(self, st, "host to device copy");
+	la_gz_batch bt;
+	memset(&bt, 0, sizeof(bt));
+	bt.d_src = st->d_src; bt.src_bytes = src_len;
+	bt.d_members = (const la_gz_member *)(T + o_mem); bt.n_members = n;
+	bt.d_dst = st->d_dst; bt.dst_cap = x->max_out;
+	bt.d_results = (la_gz_result *)(T + o_res);
+	bt.d_summary = (la_batch_summary *)(T + o_sum);
+	if (la_gpu_gzip_decode(st->gpu, &bt) != LA_OK)
+		return gz_gpu_fail(self, st, "la_gpu_gzip_decode");
+	if (st->h_res_cap < n) {
+		free(st->h_res);
+		st->h_res = malloc((size_t)n * sizeof(la_gz_result));
+		st->h_res_cap = st->h_res ? n : 0;
+		if (!st->h_res) {
+			archive_set_error(&self->archive->archive, ENOMEM, "Can't allocate data for gzip decompression");
+			return ARCHIVE_FATAL;
+		}
+	}
+	if (la_gpu_memcpy_d2h(st->gpu, st->h_res, T + o_res, (size_t)n * sizeof(la_gz_result)) != LA_OK ||
+	    la_gpu_sync(st->gpu) != LA_OK)
+		return gz_gpu_fail(self, st, "result copy");
+
+	/* ---- stream-order walk ---- */
+	uint64_t total = st->total_out;		/* stream offset of the next decoded byte */
+	uint64_t cutoff = UINT64_MAX;		/* deliver only up to here (set when an error follows) */
+	uint32_t take = 0;			/* members whose bytes join the slab */
+	uint32_t last_out = 0;			/* bytes of a failing member that still count as produced */
+	int contiguous = 1;
+	int stop = 0;
+	*used = src_len;
+	const uint32_t prev_skip = st->hint_skip, prev_cap = st->hint_cap;
+	st->hint_skip = st->hint_cap = 0;
+	for (uint32_t i = 0; i < n && !stop; i++) {
+		const la_gz_result *r = &st->h_res[i];
+		const la_gz_member *m = &x->members[i];
+		const la_gz_header *h = &x->headers[i];
+		const uint64_t member_start = h->off;
+
+		/* The deflate stream ran into the end of its span although more input exists:
+		 * the boundary (a 1f 8b 08 guess, or a wrong BGZF size) was not the member's
+		 * end.  Decode this member again with the span extended past it. */
+		if (r->status == LA_ST_GZ_TRUNCATED &&
+		    (m->src_off + m->src_len < st->stage_len || !st->upstream_eof)) {
+			*used = (size_t)member_start;
+			st->hint_skip = (i == 0 ? prev_skip : 0) + 1;
+			st->hint_cap = i == 0 ? prev_cap : 0;
+			stop = 1;
+			break;
+		}
+		if (r->status == LA_ST_GZ_OUT_FULL) {
+			/* the ISIZE claim was too small for what the member really holds */
+			*used = (size_t)member_start;
+			uint32_t base = m->dst_cap > prev_cap ? m->dst_cap : prev_cap;
+			st->hint_cap = base < 32768 ? 65536 : (base > 0x7FFFFFFFu ? 0xFFFFFFFFu : base * 2);
+			st->hint_skip = i == 0 ? prev_skip : 0;
+			stop = 1;
+			break;
+		}
+		if (r->status == LA_ST_GZ_NO_TRAILER && !st->upstream_eof) {
+			/* the trailer lies beyond this window */
+			*used = (size_t)member_start;
+			stop = 1;
+			break;
+		}
+		/* header metadata: parsed by the reference while the first 64 KiB were produced */
+		if (total < OUT_BLOCK) {
+			st->mtime = h->mtime;
+			if (h->name_off) {
+				free(st->name);
+				st->name = strdup((const char *)st->stage + h->off + h->name_off);
+			}
+		}
+		switch (r->status) {
+		case LA_ST_OK:
+		case LA_ST_GZ_BAD_CRC:
+		case LA_ST_GZ_BAD_ISIZE:
+			if (st->strict && r->status != LA_ST_OK) {
+				gz_set_fatal(st, la_status_message(r->status));
+				cutoff = total;	/* new behaviour: everything before the bad member, then the error */
+				stop = 1;
+				break;
+			}
+			if (r->out_len != m->dst_cap)
+				contiguous = 0;
+			take = i + 1;
+			total += r->out_len;
+			if (x->speculative && !h->bgzf_size && (uint64_t)r->consumed + 8 < m->src_len) {
+				/* bytes after the trailer are not a member header: silent end (gzip.c:351-353) */
+				st->eof = 1;
+				stop = 1;
+			}
+			break;
+		case LA_ST_GZ_DATA:
+			gz_set_fatal(st, "gzip decompression failed");
+			cutoff = r->out_len == 0 ? (total / OUT_BLOCK) * OUT_BLOCK
+			    : ((total + r->out_len - 1) / OUT_BLOCK) * OUT_BLOCK;
+			last_out = r->out_len;
+			take = i + 1;
+			stop = 1;
+			break;
+		case LA_ST_GZ_TRUNCATED:
+			gz_set_fatal(st, "truncated gzip input");
+			cutoff = ((total + r->out_len) / OUT_BLOCK) * OUT_BLOCK;
+			last_out = r->out_len;
+			take = i + 1;
+			stop = 1;
+			break;
+		case LA_ST_GZ_NO_TRAILER:
+			gz_set_fatal(st, NULL);	/* ARCHIVE_FATAL without a message (gzip.c:419-421) */
+			cutoff = r->out_len == 0 ? (total / OUT_BLOCK) * OUT_BLOCK
+			    : ((total + r->out_len - 1) / OUT_BLOCK) * OUT_BLOCK;
+			last_out = r->out_len;
+			take = i + 1;
+			stop = 1;
+			break;
+		default:
+			gz_set_fatal(st, "gzip decompression failed");
+			cutoff = total;
+			stop = 1;
+			break;
+		}
+	}
+	if (!stop) {
+		/* every member of the window is fine: what comes after it? */
+		if (x->end_kind == LA_END_EOF)
+			st->eof = 1;
+		else if (x->end_kind == LA_END_TRUNCATED) {
+			gz_set_fatal(st, "truncated gzip input");
+			cutoff = (total / OUT_BLOCK) * OUT_BLOCK;
+		}
+	}
+
+	/* ---- bring the bytes of members [0, take) behind the carry ---- */
+	uint64_t new_bytes = (total - st->total_out) + last_out;
+	if (gz_grow_pinned(st, &st->slab, &st->slab_cap, st->carry_len + (size_t)new_bytes + 16, st->carry_len) < 0)
+		return gz_gpu_fail(self, st, "pinned slab allocation");
+	uint8_t *dstp = st->slab + st->carry_len;
+	if (take) {
+		if (contiguous && last_out == 0) {
+			if (la_gpu_memcpy_d2h(st->gpu, dstp, st->d_dst, (size_t)new_bytes) != LA_OK)
+				return gz_gpu_fail(self, st, "device to host copy");
+		} else {
+			size_t w = 0;
+			for (uint32_t i = 0; i < take; i++) {
+				size_t len = st->h_res[i].out_len;
+				if (len && la_gpu_memcpy_d2h(st->gpu, dstp + w, (uint8_t *)st->d_dst + x->members[i].dst_off, len) != LA_OK)
+					return gz_gpu_fail(self, st, "device to host copy");
+				w += len;
+			}
+		}
+		if (la_gpu_sync(st->gpu) != LA_OK)
+			return gz_gpu_fail(self, st, "device to host copy");
+	}
+	st->total_out = total + last_out;
+	st->carry_len += (size_t)new_bytes;
+
+	/* how much of [carry | new bytes] may go out now */
+	uint64_t slab_start = st->total_out - st->carry_len;	/* stream offset of slab[0] */
+	uint64_t lim;
+	if (cutoff != UINT64_MAX)
+		lim = cutoff;					/* an error follows: the reference's count */
+	else if (st->eof)
+		lim = st->total_out;				/* clean end: everything */
+	else
+		lim = (st->total_out / OUT_BLOCK) * OUT_BLOCK;	/* keep the partial last block back */
+	if (lim < slab_start)
+		lim = slab_start;
+	st->last_ret = (size_t)(lim - slab_start);
+	return 0;
+}
+
+static ssize_t gzip_filter_read(struct archive_read_filter *self, const void **p)
+{
+	struct gzip_private *st = (struct gzip_private *)self->data;
+	*p = NULL;
+
+	/* the bytes handed out last time are released now: close the gap */
+	if (st->last_ret) {
+		memmove(st->slab, st->slab + st->last_ret, st->carry_len - st->last_ret);
+		st->carry_len -= st->last_ret;
+		st->last_ret = 0;
+	}
+	for (;;) {
+		if (st->pending_fatal) {
+			if (st->pending_has_msg)
+				archive_set_error(&self->archive->archive, ARCHIVE_ERRNO_MISC, "%s", st->pending_msg);
+			return ARCHIVE_FATAL;
+		}
+		if (st->eof) {
+			if (st->carry_len) {	/* the held-back tail of a clean stream */
+				st->last_ret = st->carry_len;
+				*p = st->slab;
+				return (ssize_t)st->carry_len;
+			}
+			return 0;
+		}
+		while (!st->upstream_eof && st->stage_len < st->batch_bytes) {
+			ssize_t avail;
+			const void *up = __archive_read_filter_ahead(self->upstream, 1, &avail);
+			if (up == NULL) {
+				if (avail < 0)
+					return ARCHIVE_FATAL;
+				st->upstream_eof = 1;
+				break;
+			}
+			size_t n = (size_t)avail;
+			if (n > st->batch_bytes - st->stage_len)
+				n = st->batch_bytes - st->stage_len;
+			if (gz_grow_pinned(st, &st->stage, &st->stage_cap, st->stage_len + n, st->stage_len) < 0)
+				return gz_gpu_fail(self, st, "pinned staging allocation");
+			memcpy(st->stage + st->stage_len, up, n);
+			st->stage_len += n;
+			__archive_read_filter_consume(self->upstream, (int64_t)n);
+		}
+		la_gz_index idx;
+		if (la_gz_index_build2(st->stage, st->stage_len, st->upstream_eof, st->hint_skip, st->hint_cap, &idx) != 0) {
+			archive_set_error(&self->archive->archive, ENOMEM, "Can't allocate data for gzip decompression");
+			return ARCHIVE_FATAL;
+		}
+		if (idx.n == 0) {
+			int kind = idx.end_kind;
+			la_gz_index_free(&idx);
+			if (kind == LA_END_NEED_MORE) {
+				if (st->upstream_eof) { st->eof = 1; continue; }
+				st->batch_bytes *= 2;	/* one member larger than the window */
+				continue;
+			}
+			if (kind == LA_END_TRUNCATED)
+				gz_set_fatal(st, "truncated gzip input");
+			else
+				st->eof = 1;
+			continue;
+		}
+		size_t used = 0;
+		int rc = gzip_run_batch(self, st, &idx, &used);
+		int made_progress = used > 0;
+		la_gz_index_free(&idx);
+		if (rc < 0)
+			return rc;
+		if (used < st->stage_len)
+			memmove(st->stage, st->stage + used, st->stage_len - used);
+		st->stage_len -= used;
+		if (!made_progress && !st->pending_fatal && !st->eof && st->hint_skip == 0 && st->hint_cap == 0) {
+			/* nothing could be finished in this window: it has to grow */
+			if (st->upstream_eof) { st->eof = 1; continue; }
+			st->batch_bytes *= 2;
+		}
+		if (st->last_ret) {
+			*p = st->slab;
+			return (ssize_t)st->last_ret;
+		}
+	}
+}
+
+static int gzip_filter_close(struct archive_read_filter *self)
+{
+	struct gzip_private *st = (struct gzip_private *)self->data;
+	if (st == NULL)
+		return ARCHIVE_OK;
+	if (st->gpu) {
+		la_gpu_sync(st->gpu);
+		if (st->stage) la_gpu_free_host(st->gpu, st->stage);
+		if (st->slab) la_gpu_free_host(st->gpu, st->slab);
+		if (st->d_src) la_gpu_free(st->gpu, st->d_src);
+		if (st->d_dst) la_gpu_free(st->gpu, st->d_dst);
+		if (st->d_tabs) la_gpu_free(st->gpu, st->d_tabs);
+		la_gpu_close(st->gpu);
+	}
+	free(st->h_res);
+	free(st->name);
+	free(st);
+	self->data = NULL;
+	return ARCHIVE_OK;
+}

@@ -1,0 +1,385 @@
+/*
+ * la_filter_lz4.c -- the lz4 read filter with an MI355X data plane.
+ *
+ * Drop-in for libarchive/archive_read_support_filter_lz4.c: same public entry
+ * point (archive_read_support_filter_lz4, lz4.c:113-129), same bidder
+ * (lz4.c:138-183), same filter name/code, same vtable shape {read, close}
+ * (lz4.c:209-213), same return codes and error strings.  What changes is the
+ * inside of read(): instead of one LZ4_decompress_safe + XXH32 per call it
+ *   1. gathers a large window of the compressed stream from upstream
+ *      (__archive_read_filter_ahead / _consume, unchanged contracts),
+ *   2. walks the frame / block headers on the host (la_lz4_index_build),
+ *   3. ships window + job tables to the GPU (la_gpu_lz4_decode: block
+ *      checksums, decode, content checksums, header check bytes),
+ *   4. returns the decoded slab (a host buffer that stays valid until the next
+ *      read(), as the vtable contract requires -- archive_read_private.h:76-83,
+ *      archive_read.c:1413-1415).
+ * Errors are reported in STREAM order: blocks before the failing one are
+ * delivered by one read(), the following read() returns ARCHIVE_FATAL with the
+ * reference's message for that failure.
+ *
+ * There is no CPU decode path: without a usable GPU, init() fails the open.
+ *
+ * Environment (read filters take no options, archive_read_set_options.c:110-123):
+ *   LA_GPU_DEVICE     device ordinal (default 0)
+ *   LA_GPU_BATCH_MIB  compressed bytes gathered per batch (default 256)
+ */
+#include "la_read_private.h"
+#include "../../include/la_gpu.h"
+#include "../../include/la_host.h"
+#include <errno.h>
+#include <stdio.h>
+
+struct lz4_private {
+	la_gpu_ctx *gpu;
+	/* compressed window (pinned host memory) */
+	uint8_t *stage;
+	size_t stage_cap, stage_len;
+	size_t batch_bytes;
+	int upstream_eof;
+	/* device buffers, grown on demand */
+	void *d_src, *d_dst, *d_tabs;
+	size_t d_src_cap, d_dst_cap, d_tabs_cap;
+	/* decoded slab handed to the read core (pinned host memory) */
+	uint8_t *slab;
+	size_t slab_cap;
+	/* host copies of per-unit results (only fetched when a batch has an event) */
+	uint32_t *h_u32;
+	size_t h_u32_cap;
+	/* what the NEXT read() must report */
+	int pending_fatal;
+	char pending_msg[128];
+	int eof;
+};
+
+static int lz4_reader_bid(struct archive_read_filter_bidder *, struct archive_read_filter *);
+static int lz4_reader_init(struct archive_read_filter *);
+static ssize_t lz4_filter_read(struct archive_read_filter *, const void **);
+static int lz4_filter_close(struct archive_read_filter *);
+
+static const struct archive_read_filter_bidder_vtable lz4_bidder_vtable = {
+	.bid = lz4_reader_bid,
+	.init = lz4_reader_init,
+};
+
+static const struct archive_read_filter_vtable lz4_reader_vtable = {
+	.read = lz4_filter_read,
+	.close = lz4_filter_close,
+};
+
+int archive_read_support_filter_lz4(struct archive *_a)
+{
+	struct archive_read *a = (struct archive_read *)_a;
+	if (__archive_read_register_bidder(a, NULL, "lz4", &lz4_bidder_vtable) != ARCHIVE_OK)
+		return ARCHIVE_FATAL;
+	return ARCHIVE_OK;
+}
+
+/* lz4.c:138-183: needs 11 bytes; 48 bits for a frame header, 32 for legacy */
+static int lz4_reader_bid(struct archive_read_filter_bidder *self, struct archive_read_filter *filter)
+{
+	ssize_t avail;
+	(void)self;
+	const unsigned char *p = __archive_read_filter_ahead(filter, 11, &avail);
+	if (p == NULL)
+		return 0;
+	return la_lz4_bid_bytes(p, 11);
+}
+
+static int gpu_fail(struct archive_read_filter *self, struct lz4_private *st, const char *what)
+{
+	archive_set_error(&self->archive->archive, ARCHIVE_ERRNO_MISC,
+	    "lz4 GPU data plane: %s failed: %s", what, st->gpu ? la_gpu_last_error(st->gpu) : "no device");
+	return ARCHIVE_FATAL;
+}
+
+static int lz4_reader_init(struct archive_read_filter *self)
+{
+	self->code = ARCHIVE_FILTER_LZ4;
+	self->name = "lz4";
+
+	struct lz4_private *st = calloc(1, sizeof(*st));
+	if (st == NULL) {
+		archive_set_error(&self->archive->archive, ENOMEM, "Can't allocate data for lz4 decompression");
+		return ARCHIVE_FATAL;
+	}
+	const char *dev = getenv("LA_GPU_DEVICE");
+	const char *bm = getenv("LA_GPU_BATCH_MIB");
+	st->batch_bytes = (size_t)(bm && atoi(bm) > 0 ? atoi(bm) : 256) << 20;
+	int rc = la_gpu_open(dev ? atoi(dev) : 0, &st->gpu);
+	if (rc != LA_OK) {
+		archive_set_error(&self->archive->archive, ARCHIVE_ERRNO_MISC,
+		    "Can't initialize lz4 GPU data plane (la_gpu_open: %d); no CPU fallback is built", rc);
+		free(st);
+		return ARCHIVE_FATAL;
+	}
+	self->data = st;
+	self->vtable = &lz4_reader_vtable;
+	return ARCHIVE_OK;
+}
+
+static int grow_pinned(struct lz4_private *st, uint8_t **p, size_t *cap, size_t need, size_t keep)
+{
+	if (*cap >= need)
+		return 0;
+	size_t nc = *cap ? *cap : (1u << 20);
+	while (nc < need)
+		nc *= 2;
+	void *np = NULL;
+	if (la_gpu_malloc_host(st->gpu, &np, nc) != LA_OK)
+		return -1;
+	if (keep)
+		memcpy(np, *p, keep);
+	if (*p)
+		la_gpu_free_host(st->gpu, *p);
+	*p = np;
+	*cap = nc;
+	return 0;
+}
+
+static int grow_dev(struct lz4_private *st, void **p, size_t *cap, size_t need)
+{
+	if (*cap >= need)
+		return 0;
+	size_t nc = *cap ? *cap : (1u << 20);
+	while (nc < need)
+		nc *= 2;
+	if (*p)
+		la_gpu_free(st->gpu, *p);
+	*p = NULL;
+	*cap = 0;
+	if (la_gpu_malloc(st->gpu, p, nc) != LA_OK)
+		return -1;
+	*cap = nc;
+	return 0;
+}
+
+#define ALIGN256(x) (((x) + 255) & ~(size_t)255)
+
+/*
+ * One batch.  Returns bytes delivered into st->slab (>= 0) or ARCHIVE_FATAL;
+ * sets st->eof / st->pending_fatal for what follows those bytes.
+ */
+static ssize_t lz4_run_batch(struct archive_read_filter *self, struct lz4_private *st,
+    const la_lz4_index *x)
+{
+	const uint32_t nb = x->n_blocks, nf = x->n_frames;
+	const size_t src_len = (size_t)x->consumed;
+
+	if (nb == 0 && nf == 0) {
+		/* only skippable frames / trailing bytes in this window: nothing for the device */
+		switch (x->end_kind) {
+		case LA_END_TRUNCATED: case LA_END_MALFORMED: case LA_END_MALFORMED_SKIP:
+			st->pending_fatal = 1;
+			snprintf(st->pending_msg, sizeof(st->pending_msg), "%s", la_end_message(x->end_kind, 0));
+			break;
+		case LA_END_EOF: case LA_END_EMPTY_FRAME:
+			st->eof = 1;
+			break;
+		default:
+			break;
+		}
+		return 0;
+	}
+
+	/* layout of the table buffer on the device */
+	size_t o = 0;
+	const size_t o_blocks = o; o += ALIGN256((size_t)nb * sizeof(la_lz4_block));
+	const size_t o_frames = o; o += ALIGN256((size_t)nf * sizeof(la_lz4_frame));
+	const size_t o_outlen = o; o += ALIGN256((size_t)nb * 4);
+	const size_t o_dstoff = o; o += ALIGN256(((size_t)nb + 1) * 8);
+	const size_t o_bst = o; o += ALIGN256((size_t)nb * 4);
+	const size_t o_fst = o; o += ALIGN256((size_t)nf * 4);
+	const size_t o_sum = o; o += 256;
+	if (grow_dev(st, &st->d_src, &st->d_src_cap, src_len + 64) < 0 ||
+	    grow_dev(st, &st->d_dst, &st->d_dst_cap, (size_t)x->max_out + 64) < 0 ||
+	    grow_dev(st, &st->d_tabs, &st->d_tabs_cap, o) < 0)
+		return gpu_fail(self, st, "device allocation");
+	uint8_t *T = st->d_tabs;
+
+	if (la_gpu_memcpy_h2d(st->gpu, st->d_src, st->stage, src_len) != LA_OK ||
+	    la_gpu_memcpy_h2d(st->gpu, T + o_blocks, x->blocks, (size_t)nb * sizeof(la_lz4_block)) != LA_OK ||
+	    la_gpu_memcpy_h2d(st->gpu, T + o_frames, x->frames, (size_t)nf * sizeof(la_lz4_frame)) != LA_OK)
+		return gpu_fail(self, st, "host to device copy");
+
+	la_lz4_batch bt;
+	memset(&bt, 0, sizeof(bt));
+	bt.d_src = st->d_src; bt.src_bytes = src_len;
+	bt.d_blocks = (const la_lz4_block *)(T + o_blocks); bt.n_blocks = nb;
+	bt.d_frames = nf ? (const la_lz4_frame *)(T + o_frames) : NULL; bt.n_frames = nf;
+	bt.d_dst = st->d_dst; bt.dst_cap = x->max_out;
+	bt.d_out_len = (uint32_t *)(T + o_outlen);
+	bt.d_dst_off = (uint64_t *)(T + o_dstoff);
+	bt.d_block_status = (uint32_t *)(T + o_bst);
+	bt.d_frame_status = (uint32_t *)(T + o_fst);
+	bt.d_summary = (la_batch_summary *)(T + o_sum);
+	if (la_gpu_lz4_decode(st->gpu, &bt) != LA_OK)
+		return gpu_fail(self, st, "la_gpu_lz4_decode");
+
+	la_batch_summary sm;
+	if (la_gpu_memcpy_d2h(st->gpu, &sm, T + o_sum, sizeof(sm)) != LA_OK || la_gpu_sync(st->gpu) != LA_OK)
+		return gpu_fail(self, st, "summary copy");
+
+	uint64_t delivered = sm.total_out;
+	uint32_t st_code = LA_ST_OK;
+	int silent_end = 0;
+
+	if (sm.n_bad_units || sm.n_bad_frames || sm.first_zero_unit != 0xFFFFFFFFu) {
+		/* Something happened: fetch the per-unit words and find the FIRST event in
+		 * stream order (per frame: header check -> blocks -> content checksum). */
+		size_t words = (size_t)nb * 2 + (size_t)nf + ((size_t)nb + 1) * 2 + 2;
+		if (st->h_u32_cap < words) {
+			free(st->h_u32);
+			st->h_u32 = malloc(words * 4);
+			st->h_u32_cap = st->h_u32 ? words : 0;
+			if (!st->h_u32) {
+				archive_set_error(&self->archive->archive, ENOMEM, "Can't allocate data for lz4 decompression");
+				return ARCHIVE_FATAL;
+			}
+		}
+		uint32_t *h_len = st->h_u32, *h_bst = h_len + nb, *h_fst = h_bst + nb;
+		uint64_t *h_off = (uint64_t *)(h_fst + nf + ((nb * 2 + nf) & 1));
+		if (la_gpu_memcpy_d2h(st->gpu, h_len, T + o_outlen, (size_t)nb * 4) != LA_OK ||
+		    la_gpu_memcpy_d2h(st->gpu, h_bst, T + o_bst, (size_t)nb * 4) != LA_OK ||
+		    la_gpu_memcpy_d2h(st->gpu, h_fst, T + o_fst, (size_t)nf * 4) != LA_OK ||
+		    la_gpu_memcpy_d2h(st->gpu, h_off, T + o_dstoff, ((size_t)nb + 1) * 8) != LA_OK ||
+		    la_gpu_sync(st->gpu) != LA_OK)
+			return gpu_fail(self, st, "status copy");
+		int found = 0;
+		for (uint32_t fi = 0; fi < nf && !found; fi++) {
+			const la_lz4_frame *f = &x->frames[fi];
+			if (h_fst[fi] == LA_ST_LZ4_BAD_HEADER_SUM) {
+				delivered = h_off[f->first_block]; st_code = h_fst[fi]; found = 1;
+				break;
+			}
+			for (uint32_t b = f->first_block; b < f->first_block + f->n_blocks; b++) {
+				if (h_bst[b] != LA_ST_OK) {
+					delivered = h_off[b]; st_code = h_bst[b]; found = 1;
+					break;
+				}
+				if (h_len[b] == 0) {	/* a block of 0 bytes is EOF to the read core (SURVEY F11 i) */
+					delivered = h_off[b]; silent_end = 1; found = 1;
+					break;
+				}
+			}
+			if (!found && h_fst[fi] == LA_ST_LZ4_BAD_CONTENT_SUM) {
+				delivered = h_off[f->first_block + f->n_blocks]; st_code = h_fst[fi]; found = 1;
+			}
+		}
+	}
+
+	if (st_code != LA_ST_OK) {
+		st->pending_fatal = 1;
+		snprintf(st->pending_msg, sizeof(st->pending_msg), "%s", la_status_message(st_code));
+	} else if (silent_end) {
+		st->eof = 1;
+	} else {
+		switch (x->end_kind) {
+		case LA_END_TRUNCATED:
+		case LA_END_MALFORMED:
+		case LA_END_MALFORMED_SKIP:
+			st->pending_fatal = 1;
+			snprintf(st->pending_msg, sizeof(st->pending_msg), "%s", la_end_message(x->end_kind, 0));
+			break;
+		case LA_END_EOF:
+		case LA_END_EMPTY_FRAME:
+			st->eof = 1;
+			break;
+		default:	/* LA_END_NEED_MORE: the stream goes on in the next batch */
+			break;
+		}
+	}
+
+	if (delivered) {
+		if (grow_pinned(st, &st->slab, &st->slab_cap, (size_t)delivered, 0) < 0)
+			return gpu_fail(self, st, "pinned slab allocation");
+		if (la_gpu_memcpy_d2h(st->gpu, st->slab, st->d_dst, (size_t)delivered) != LA_OK ||
+		    la_gpu_sync(st->gpu) != LA_OK)
+			return gpu_fail(self, st, "device to host copy");
+	}
+	return (ssize_t)delivered;
+}
+
+static ssize_t lz4_filter_read(struct archive_read_filter *self, const void **p)
+{
+	struct lz4_private *st = (struct lz4_private *)self->data;
+	*p = NULL;
+
+	for (;;) {
+		if (st->pending_fatal) {
+			archive_set_error(&self->archive->archive, ARCHIVE_ERRNO_MISC, "%s", st->pending_msg);
+			return ARCHIVE_FATAL;
+		}
+		if (st->eof)
+			return 0;
+
+		/* 1. gather compressed bytes until the window is full or upstream ends */
+		while (!st->upstream_eof && st->stage_len < st->batch_bytes) {
+			ssize_t avail;
+			const void *up = __archive_read_filter_ahead(self->upstream, 1, &avail);
+			if (up == NULL) {
+				if (avail < 0)
+					return ARCHIVE_FATAL;	/* upstream already set the error */
+				st->upstream_eof = 1;
+				break;
+			}
+			size_t n = (size_t)avail;
+			if (n > st->batch_bytes - st->stage_len)
+				n = st->batch_bytes - st->stage_len;
+			if (grow_pinned(st, &st->stage, &st->stage_cap, st->stage_len + n, st->stage_len) < 0)
+				return gpu_fail(self, st, "pinned staging allocation");
+			memcpy(st->stage + st->stage_len, up, n);
+			st->stage_len += n;
+			__archive_read_filter_consume(self->upstream, (int64_t)n);
+		}
+
+		/* 2. frame / block headers (host pointer chase, no payload byte touched) */
+		la_lz4_index idx;
+		if (la_lz4_index_build(st->stage, st->stage_len, st->upstream_eof, &idx) != 0) {
+			archive_set_error(&self->archive->archive, ENOMEM, "Can't allocate data for lz4 decompression");
+			return ARCHIVE_FATAL;
+		}
+		if (idx.end_kind == LA_END_NEED_MORE && idx.n_blocks == 0 && idx.n_frames == 0 && idx.consumed == 0) {
+			/* a single frame larger than the window: widen the window and gather more */
+			la_lz4_index_free(&idx);
+			st->batch_bytes *= 2;
+			continue;
+		}
+
+		/* 3. + 4. device batch and stream-order outcome */
+		ssize_t n = lz4_run_batch(self, st, &idx);
+		size_t used = (size_t)idx.consumed;
+		la_lz4_index_free(&idx);
+		if (n < 0)
+			return n;
+		/* keep the unconsumed tail (an incomplete frame) for the next batch */
+		if (used < st->stage_len)
+			memmove(st->stage, st->stage + used, st->stage_len - used);
+		st->stage_len -= used;
+		if (n > 0) {
+			*p = st->slab;
+			return n;
+		}
+		/* nothing to deliver from this batch: report what follows, or go on */
+	}
+}
+
+static int lz4_filter_close(struct archive_read_filter *self)
+{
+	struct lz4_private *st = (struct lz4_private *)self->data;
+	if (st == NULL)
+		return ARCHIVE_OK;
+	if (st->gpu) {
+		la_gpu_sync(st->gpu);
+		if (st->stage) la_gpu_free_host(st->gpu, st->stage);
+		if (st->slab) la_gpu_free_host(st->gpu, st->slab);
+		if (st->d_src) la_gpu_free(st->gpu, st->d_src);
+		if (st->d_dst) la_gpu_free(st->gpu, st->d_dst);
+		if (st->d_tabs) la_gpu_free(st->gpu, st->d_tabs);
+		la_gpu_close(st->gpu);
+	}
+	free(st->h_u32);
+	free(st);
+	self->data = NULL;
+	return ARCHIVE_OK;
+}

@@ -1,0 +1,155 @@
+"""GPU: the two filters behind the reference's own API shape (archive_read_open_memory2 ->
+archive_read_next_header -> archive_read_data_block), checked against the oracle's
+restatement of the reference filters: bytes, return code, error string, filter
+code/name/count, entry metadata.  Reader block sizes 1 / 2 / 200 exercise the core's
+copy-buffer paths the way the reference's tests do (test_compat_lz4.c:59)."""
+import hashlib
+import json
+import os
+import random
+
+import pytest
+
+import la_api
+import oracle_lib as O
+import streams as S
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_fixtures")
+MANIFEST = json.load(open(os.path.join(GOLD, "manifest.json")))
+
+
+def oracle_tuple(img, codec):
+    fn = O.lz4_stream_decode if codec == "lz4" else O.gzip_stream_decode
+    out, res = fn(img, 1 << 24)
+    return (out.tobytes(), res.rc, res.errmsg.decode()), res
+
+
+@pytest.mark.parametrize("entry", MANIFEST, ids=[e["file"] for e in MANIFEST])
+@pytest.mark.parametrize("read_size", [None, 200])
+def test_reference_fixtures_through_the_api(gpu_ctx, entry, read_size):
+    data = open(os.path.join(GOLD, entry["file"]), "rb").read()
+    r = la_api.cat(data, read_size=read_size)
+    assert r.open_rc == 0 and r.rc == la_api.ARCHIVE_EOF and r.error is None
+    assert len(r.data) == entry["decoded_size"]
+    assert hashlib.sha256(r.data).hexdigest() == entry["decoded_sha256"]
+    code, name = (13, "lz4") if entry["codec"] == "lz4" else (1, "gzip")
+    if entry["decoded_size"] or entry["codec"] == "gzip":
+        assert r.filters == [(code, name), (0, "none")]          # archive_filter_code(a,0), name (test_compat_lz4.c)
+        assert r.bytes_in == len(data) or entry["file"].endswith(("_2.tar.lz4", "_2.tgz"))
+
+
+def test_gzip_entry_metadata_from_fixture(gpu_ctx):
+    # libarchive/test/test_read_format_raw.c:122-148
+    data = open(os.path.join(GOLD, "test_read_format_raw.data.gz"), "rb").read()
+    for rs in (None, 1, 2):
+        r = la_api.cat(data, read_size=rs)
+        assert (r.data, r.pathname, r.mtime) == (b"foo\n", "test-file-name.data", 0x5CBAFD25)
+
+
+@pytest.mark.parametrize("name", sorted(S.appendix_d_lz4_cases()))
+def test_lz4_behaviour_table_through_the_api(gpu_ctx, name):
+    img, want, rc, msg = S.appendix_d_lz4_cases()[name]
+    r = la_api.cat(img)
+    if r.filters and r.filters[0][1] != "lz4":
+        pytest.skip("not claimed by the lz4 bidder")
+    assert la_api.as_reference_tuple(r) == (want, rc, msg)
+
+
+def test_lz4_small_reader_blocks_and_read_data(gpu_ctx):
+    img, plain = S.synth_lz4_stream(3, 0, 5, blocks_per_frame=3, block_size=7001, nthreads=1)
+    for rs in (1, 2, 200, 4096, None):
+        r = la_api.cat(img.tobytes(), read_size=rs)
+        assert la_api.as_reference_tuple(r) == (plain.tobytes(), 0, "")
+    r = la_api.cat(img.tobytes(), use_read_data=777)
+    assert r.data == plain.tobytes()
+
+
+def test_lz4_multiple_batches(gpu_ctx, monkeypatch):
+    monkeypatch.setenv("LA_GPU_BATCH_MIB", "1")
+    img, plain = S.synth_lz4_stream(4, 0, 40, blocks_per_frame=4, block_size=65536, nthreads=4)
+    r = la_api.cat(img.tobytes(), read_size=65536)
+    assert la_api.as_reference_tuple(r) == (plain.tobytes(), 0, "")
+    assert len(r.block_sizes) > 3
+    # an error in a late batch is reported after everything before it
+    bad = bytearray(img.tobytes())
+    bad[-100] ^= 0xFF
+    ref, _ = oracle_tuple(bytes(bad), "lz4")
+    assert la_api.as_reference_tuple(la_api.cat(bytes(bad), read_size=65536)) == ref
+
+
+def test_lz4_file_reader(gpu_ctx, tmp_path):
+    img, plain = S.synth_lz4_stream(8, 0, 6, blocks_per_frame=4, block_size=65536, nthreads=2)
+    f = tmp_path / "x.lz4"
+    f.write_bytes(img.tobytes())
+    r = la_api.cat(None, filename=str(f))
+    assert r.data == plain.tobytes() and r.filters[0] == (13, "lz4")
+
+
+def _gz_cases():
+    P = (b"All work and no play makes Jack a dull boy.\n" * 41)[:1800]
+    import zlib
+    m = S.gz_member(P)
+    cases = {
+        "valid": m, "level0": S.gz_member(P, level=0), "fixed": S.gz_member(P, strategy=zlib.Z_FIXED),
+        "all_header_fields": S.gz_member(P, name=b"n", comment=b"c", extra=b"BC\x02\x00\x10\x00", hcrc=True),
+        "bad_crc_accepted": S.gz_member(P, bad_crc=True), "bad_isize_accepted": S.gz_member(P, bad_isize=True),
+        "three_members": m + S.gz_member(b"0123456789abc") + S.gz_member(b""),
+        "junk_after": m + b"arbitrary junk", "junk_1f": m + b"\x1f", "junk_magic": m + b"\x1f\x8b\x08",
+        "reserved_flag_second": m + b"\x1f\x8b\x08\x20" + m[4:],
+        "cut_body_40": m[:40], "cut_last_body_byte": m[:-9], "trailer_4_of_8": m[:-4], "trailer_missing": m[:-8],
+        "empty_member_only": S.gz_member(b""),
+        "big_members": S.gz_member(os.urandom(70000)) + S.gz_member(b"z" * 200000) + S.gz_member(os.urandom(10)),
+    }
+    body = bytearray(S.gz_member(P * 40))
+    body[300] ^= 0x10
+    body[301] ^= 0x01
+    cases["corrupt_body"] = bytes(body)
+    cases["good_then_corrupt"] = S.gz_member(os.urandom(50000)) + S.gz_member(os.urandom(30000)) + bytes(body)
+    return cases
+
+
+@pytest.mark.parametrize("name", sorted(_gz_cases()))
+def test_gzip_behaviour_table_through_the_api(gpu_ctx, name):
+    img = _gz_cases()[name]
+    ref, res = oracle_tuple(img, "gzip")
+    for rs in (None, 200):
+        r = la_api.cat(img, read_size=rs)
+        assert la_api.as_reference_tuple(r) == ref, (name, rs)
+
+
+def test_gzip_metadata_snapshot(gpu_ctx):
+    def three(n):
+        return b"".join(S.gz_member(bytes([65 + i]) * n, name=nm, mtime=mt)
+                        for i, (nm, mt) in enumerate(((b"first", 1000), (b"second", 2000), (b"third", 3000))))
+    for n, nm, mt in ((5, "third", 3000), (40000, "second", 2000)):
+        r = la_api.cat(three(n))
+        assert (r.pathname, r.mtime, len(r.data)) == (nm, mt, 3 * n)
+    img = S.gz_member(bytes(65536), name=b"first", mtime=1000) + S.gz_member(b"x", name=b"second", mtime=2000)
+    r = la_api.cat(img)
+    assert (r.pathname, r.mtime, len(r.data)) == ("first", 1000, 65537)
+
+
+def test_gzip_strict_mode_rejects_bad_crc(gpu_ctx, monkeypatch):
+    monkeypatch.setenv("LA_GZIP_STRICT", "1")
+    P = b"payload " * 500
+    r = la_api.cat(S.gz_member(b"ok" * 10) + S.gz_member(P, bad_crc=True))
+    assert r.rc == la_api.ARCHIVE_FATAL and "CRC32" in r.error
+
+
+def test_gzip_mutated_streams(gpu_ctx):
+    rnd = random.Random(6)
+    base = S.gz_member(os.urandom(3000) + b"abc" * 3000, name=b"a") + S.gz_member(b"hello world " * 700) + S.gz_member(b"tail")
+    for t in range(40):
+        m = bytearray(base)
+        for _ in range(rnd.randint(1, 3)):
+            m[rnd.randrange(len(m))] ^= 1 << rnd.randrange(8)
+        if rnd.random() < 0.3:
+            m = m[:rnd.randrange(1, len(m))]
+        m = bytes(m)
+        ref, _ = oracle_tuple(m, "gzip")
+        r = la_api.cat(m)
+        if r.filters and r.filters[0][1] != "gzip":
+            continue
+        assert la_api.as_reference_tuple(r) == ref, t
