@@ -100,16 +100,12 @@ static int gzip_bidder_bid(struct archive_read_filter_bidder *self, struct archi
 		return 0;
 	if (p[0] != 0x1f || p[1] != 0x8b || p[2] != 0x08 || (p[3] & 0xE0))
 		return 0;
-	/* optional fields: ask for more until the header parses or upstream runs dry */
-	size_t want = 10;
+	/* optional fields: like the reference's parser (gzip.c:183-194), extend the peek one
+	 * byte at a time until the header parses or upstream cannot supply another byte */
 	for (;;) {
-		size_t hl = la_gz_header_parse(p, (size_t)avail, NULL);
-		if (hl)
+		if (la_gz_header_parse(p, (size_t)avail, NULL))
 			return 27;
-		if ((size_t)avail > want)
-			want = (size_t)avail;
-		want += 256;
-		p = __archive_read_filter_ahead(filter, want, &avail);
+		p = __archive_read_filter_ahead(filter, (size_t)avail + 1, &avail);
 		if (p == NULL)
 			return 0;
 	}
