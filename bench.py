@@ -56,7 +56,7 @@ def build_tiled_stream(torch, la, S, rank, unique_mib, total_gib, device):
     from libarchive_amd import _native as N
     frames_unique = max(1, (unique_mib << 20) // (BPF * BLOCK))
     tiles = max(1, int(round(total_gib * (1 << 30) / (frames_unique * BPF * BLOCK))))
-    first_frame = rank * frames_unique  # every rank decodes different data
+    first_frame = rank * frames_unique  # every rank decodes its own frame range of the stream
     t0 = time.time()
     img, plain = S.synth_lz4_stream(SEED, first_frame, frames_unique, BPF, BLOCK,
                                     nthreads=min(16, os.cpu_count() or 1), want_plain=False)
@@ -159,19 +159,9 @@ def main():
     for t in range(1, info["tiles"]):
         ok = ok and bool(torch.equal(out0, plan.d_dst[t * tile_bytes:(t + 1) * tile_bytes]))
 
-    t_max = torch.tensor([dt], dtype=torch.float64, device=device)
-    tot = torch.tensor([float(U_bytes), float(C_bytes), 1.0 if ok else 0.0], dtype=torch.float64, device=device)
-    if world > 1:
-        # the only exchange: per-rank summaries (no decoded bytes move; outputs stay sharded)
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-        allt = [torch.zeros_like(tot) for _ in range(world)]
-        dist.all_gather(allt, tot)
-        U_all = sum(float(t[0]) for t in allt)
-        C_all = sum(float(t[1]) for t in allt)
-        ok_all = all(float(t[2]) == 1.0 for t in allt)
-    else:
-        U_all, C_all, ok_all = float(U_bytes), float(C_bytes), ok
-    dt_max = float(t_max[0])
+    # the only exchange: per-rank summaries (no decoded bytes move; outputs stay sharded)
+    from libarchive_amd.shard import exchange_summaries
+    dt_max, U_all, C_all, ok_all = exchange_summaries(dist, device, dt, U_bytes, C_bytes, ok)
 
     if rank == 0:
         cpu = None
