@@ -77,6 +77,37 @@ __device__ __forceinline__ uint64_t lds_ld_tail(const uint8_t *p, uint32_t n)
 	return v;
 }
 
+/* A sequence-table entry travels in registers as one 64-bit value
+ * (lit_src | lit_len << 16 | dst << 32 | off << 48): plain integers keep the
+ * compiler from parking small structs in scratch memory. */
+typedef uint64_t seq_t;
+
+/*
+ * Ownership of sequences in the match phase: a STEP is sixteen consecutive sequences
+ * (16g .. 16g+15); step g belongs to wave g % 8, which runs its steps in increasing
+ * order.  Register slot r of lane l in wave w holds sequence
+ *     k = (((4 r + l/16) * 8 + w) * 16) + l % 16
+ * so that the step a wave executes at (r, t) sits in lanes 16t .. 16t+15.
+ */
+#ifndef STEP_SHIFT
+#define STEP_SHIFT  2u		/* log2(sequences per step) */
+#endif
+#define STEP_SEQS   (1u << STEP_SHIFT)		/* sequences per step */
+#define STEP_LANES  (64u >> STEP_SHIFT)		/* lanes per sequence, 8 bytes each per pass */
+#define STEPS_PER_SLOT (64u >> STEP_SHIFT)	/* steps held by one register slot of a wave */
+__device__ __forceinline__ uint32_t fast_seq_index(uint32_t r, uint32_t wave, uint32_t lane)
+{
+	return (((r * STEPS_PER_SLOT + (lane >> STEP_SHIFT)) * 8 + wave) << STEP_SHIFT) + (lane & (STEP_SEQS - 1));
+}
+__device__ __forceinline__ seq_t seq_load(const la_lz4_seq *t, uint32_t k)
+{
+	return *(const uint64_t *)(const void *)(t + k);
+}
+#define SEQ_LIT_SRC(e) ((uint32_t)((e) & 0xFFFFu))
+#define SEQ_LIT_LEN(e) ((uint32_t)(((e) >> 16) & 0xFFFFu))
+#define SEQ_DST(e)     ((uint32_t)(((e) >> 32) & 0xFFFFu))
+#define SEQ_OFF(e)     ((uint32_t)((e) >> 48))
+
 template <uint32_t MAXSEQ>
 __global__ __launch_bounds__(FAST_THREADS, 4) void lz4_expand_fast_kernel(
     const uint8_t *__restrict__ src, uint64_t src_bytes, const la_lz4_block *__restrict__ blocks,
@@ -87,9 +118,9 @@ __global__ __launch_bounds__(FAST_THREADS, 4) void lz4_expand_fast_kernel(
     const uint64_t *__restrict__ lidx_off)
 {
 	const uint32_t *status = status_out;
-	__shared__ __attribute__((aligned(16))) uint8_t win[65536 + 16];
+	__shared__ __attribute__((aligned(16))) uint8_t win[65536 + 32];
 	__shared__ uint16_t dstpos[MAXSEQ + 4];
-	__shared__ uint32_t donebits[MAXSEQ / 32];
+	__shared__ uint32_t donebits[MAXSEQ / 32];	/* one bit per sequence: its match is in the window */
 
 	const uint32_t bi = blockIdx.x;
 	if (bi >= n)
@@ -111,18 +142,16 @@ __global__ __launch_bounds__(FAST_THREADS, 4) void lz4_expand_fast_kernel(
 	const uint64_t s_room = src_bytes - b.src_off;	/* bytes of the image from s on */
 	uint8_t *g_out = dst + doff;
 	uint8_t *W = win + ((uintptr_t)g_out & 15);	/* W[i] <-> g_out[i], congruent mod 16 */
-	volatile uint32_t *done_v = donebits;
 
 	/* This thread's sequences k = (r*8 + wave)*64 + lane, r = 0..MAXSTEPS-1: their table
 	 * entries are fetched once, up front, and stay in registers for both passes over
 	 * them (output positions -> LDS now, matches later). */
 	constexpr uint32_t MAXSTEPS = MAXSEQ / FAST_THREADS;
-	la_lz4_seq ent[MAXSTEPS];
+	seq_t ent[MAXSTEPS];
 #pragma unroll
 	for (uint32_t r = 0; r < MAXSTEPS; r++) {
-		const uint32_t k = (r * FAST_WAVES + wave) * 64 + lane;
-		la_lz4_seq z = { 0, 0, 0, 0 };
-		ent[r] = k < ns ? tab[k] : z;
+		const uint32_t k = fast_seq_index(r, wave, lane);
+		ent[r] = k < ns ? seq_load(tab, k) : 0;
 	}
 	if (tid < MAXSEQ / 32)
 		donebits[tid] = 0;
@@ -155,14 +184,12 @@ __global__ __launch_bounds__(FAST_THREADS, 4) void lz4_expand_fast_kernel(
 				}
 			}
 		}
-		la_lz4_seq pe[4][2];
+		seq_t pe[4][4];
 #pragma unroll
 		for (int u = 0; u < 4; u++) {
 #pragma unroll
-			for (int t = 0; t < 2; t++) {
-				la_lz4_seq z = { 0, 0, 0, 0 };
-				pe[u][t] = (kk[u] != 0xFFFFFFFFu && kk[u] + t < ns) ? tab[kk[u] + t] : z;
-			}
+			for (int t = 0; t < 4; t++)
+				pe[u][t] = (kk[u] != 0xFFFFFFFFu && kk[u] + t < ns) ? seq_load(tab, kk[u] + t) : 0;
 		}
 #pragma unroll
 		for (int u = 0; u < 4; u++) {
@@ -172,8 +199,8 @@ __global__ __launch_bounds__(FAST_THREADS, 4) void lz4_expand_fast_kernel(
 			const uint4 v = vv[u];
 			uint32_t k = kk[u];
 			for (uint32_t it = 0; k < ns; it++, k++) {
-				la_lz4_seq e = it == 0 ? pe[u][0] : it == 1 ? pe[u][1] : tab[k];
-				const uint32_t ls = e.lit_src, le = ls + e.lit_len;
+				const seq_t e = it == 0 ? pe[u][0] : it == 1 ? pe[u][1] : it == 2 ? pe[u][2] : it == 3 ? pe[u][3] : seq_load(tab, k);
+				const uint32_t ls = SEQ_LIT_SRC(e), le = ls + SEQ_LIT_LEN(e);
 				if (ls >= c1)
 					break;
 				const uint32_t lo = ls > c0 ? ls : c0, hi = le < c1 ? le : c1;
@@ -185,7 +212,7 @@ __global__ __launch_bounds__(FAST_THREADS, 4) void lz4_expand_fast_kernel(
 					if (i >= 8) { a = vhi >> (8 * (i - 8)); bq = 0; }
 					else if (i == 0) { a = vlo; bq = vhi; }
 					else { a = (vlo >> (8 * i)) | (vhi << (64 - 8 * i)); bq = vhi >> (8 * i); }
-					uint8_t *wp = W + e.dst + (lo - ls);
+					uint8_t *wp = W + SEQ_DST(e) + (lo - ls);
 					if (nb >= 8) {
 						lds_st8(wp, a);
 						if (nb == 16) lds_st8(wp + 8, bq);
@@ -200,9 +227,9 @@ __global__ __launch_bounds__(FAST_THREADS, 4) void lz4_expand_fast_kernel(
 	}
 #pragma unroll
 	for (uint32_t r = 0; r < MAXSTEPS; r++) {
-		const uint32_t k = (r * FAST_WAVES + wave) * 64 + lane;
+		const uint32_t k = fast_seq_index(r, wave, lane);
 		if (k < ns)
-			dstpos[k] = ent[r].dst;
+			dstpos[k] = (uint16_t)SEQ_DST(ent[r]);
 	}
 	STAMP(1);
 	__syncthreads();
@@ -219,8 +246,8 @@ __global__ __launch_bounds__(FAST_THREADS, 4) void lz4_expand_fast_kernel(
 #pragma unroll
 		for (uint32_t r = 0; r < MAXSTEPS; r++) {
 			/* largest idx < k with dstpos[idx] <= s0 */
-			const uint32_t k = (r * FAST_WAVES + wave) * 64 + lane;
-			const uint32_t s0 = ent[r].dst + ent[r].lit_len - ent[r].off;
+			const uint32_t k = fast_seq_index(r, wave, lane);
+			const uint32_t s0 = SEQ_DST(ent[r]) + SEQ_LIT_LEN(ent[r]) - SEQ_OFF(ent[r]);
 			const uint32_t cand = qcur[r] + bit;
 			if (cand < k && k < ns && dstpos[cand] <= s0)
 				qcur[r] = cand;
@@ -228,8 +255,8 @@ __global__ __launch_bounds__(FAST_THREADS, 4) void lz4_expand_fast_kernel(
 	}
 #pragma unroll
 	for (uint32_t r = 0; r < MAXSTEPS; r++) {
-		const uint32_t k = (r * FAST_WAVES + wave) * 64 + lane;
-		const uint32_t d = ent[r].dst, mdst = d + ent[r].lit_len, off = ent[r].off;
+		const uint32_t k = fast_seq_index(r, wave, lane);
+		const uint32_t d = SEQ_DST(ent[r]), mdst = d + SEQ_LIT_LEN(ent[r]), off = SEQ_OFF(ent[r]);
 		const uint32_t s0 = mdst - off;
 		uint32_t next = olen;
 		if (k + 1 < ns)
@@ -253,16 +280,16 @@ __global__ __launch_bounds__(FAST_THREADS, 4) void lz4_expand_fast_kernel(
 	for (uint32_t r = 0; r < MAXSTEPS; r++) {
 		if (r * FAST_THREADS >= ns)
 			break;
-		const uint32_t k = (r * FAST_WAVES + wave) * 64 + lane;
+		const uint32_t k = fast_seq_index(r, wave, lane);
 		const bool active = k < ns;
 		/* registers of step r (the array is indexed by a loop counter: pick by selects) */
-		la_lz4_seq e = ent[0];
+		seq_t e = ent[0];
 		uint32_t qp = qcur[0];
 #pragma unroll
 		for (uint32_t t = 1; t < MAXSTEPS; t++)
 			if (r == t) { e = ent[t]; qp = qcur[t]; }
-		const uint32_t off = e.off;
-		const uint32_t mdst = e.dst + e.lit_len;
+		const uint32_t off = SEQ_OFF(e);
+		const uint32_t mdst = SEQ_DST(e) + SEQ_LIT_LEN(e);
 		uint32_t next = olen;
 		if (active && k + 1 < ns)
 			next = dstpos[k + 1];
@@ -281,7 +308,7 @@ __global__ __launch_bounds__(FAST_THREADS, 4) void lz4_expand_fast_kernel(
 				while (q < qstop) {
 					/* bit 0 of `word` is the flag of q; the zeros shifted in from the
 					 * top end the run at the word boundary */
-					uint32_t word = done_v[q >> 5] >> (q & 31);
+					uint32_t word = __hip_atomic_load(&donebits[q >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> (q & 31);
 					uint32_t inv = ~word;
 					uint32_t run = inv ? (uint32_t)__builtin_ctz(inv) : 32u;
 					if (run == 0)
@@ -296,7 +323,7 @@ __global__ __launch_bounds__(FAST_THREADS, 4) void lz4_expand_fast_kernel(
 					q = qstop;
 				}
 				if (q >= qstop) {
-					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+					asm volatile("" ::: "memory");
 					uint8_t *mp = W + mdst;
 					const uint8_t *fp = W + s0;
 					if (off >= mlen) {
@@ -331,14 +358,14 @@ __global__ __launch_bounds__(FAST_THREADS, 4) void lz4_expand_fast_kernel(
 							asm volatile("" ::: "memory");	/* keep load/store order: the ranges overlap */
 						}
 						for (; i < mlen; i++)
-							((volatile uint8_t *)mp)[i] = ((volatile uint8_t *)mp)[(int)i - (int)off];
+							{ uint8_t bq = mp[(int)i - (int)off]; asm volatile("" ::: "memory"); mp[i] = bq; asm volatile("" ::: "memory"); }
 					} else {
 						/* overlapping match: replicate with period `off`; every byte
 						 * read is one this thread (or an earlier sequence) already wrote */
 						for (uint32_t i = 0; i < mlen; i++)
-							((volatile uint8_t *)mp)[i] = ((volatile uint8_t *)mp)[(int)i - (int)off];
+							{ uint8_t bq = mp[(int)i - (int)off]; asm volatile("" ::: "memory"); mp[i] = bq; asm volatile("" ::: "memory"); }
 					}
-					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+					asm volatile("" ::: "memory");
 					atomicOr(&donebits[k >> 5], 1u << (k & 31));
 					fin = true;
 				}

@@ -29,4 +29,7 @@ print("blocks %d  mean cycles per workgroup %.0f  (median %.0f)" % (nb, tot.mean
 for i, nme in enumerate(names):
     d = st[:, i + 1] - st[:, i]
     print("  %-18s mean %8.0f  median %8.0f  share %.1f%%" % (nme, d.mean(), np.median(d), 100 * d.sum() / tot.sum()))
-print("kernel span cycles:", st[:, 5].max() - st[:, 0].min())
+raw = stamps.cpu().numpy().reshape(nb, 8).astype(np.uint64)
+print("per block: steps with a slow-path dependency check %.1f, serial (hazard) steps %.1f, sub-groups that spun %.1f, spin iterations %.1f"
+      % ((raw[:, 6] >> np.uint64(32)).mean(), (raw[:, 6] & np.uint64(0xFFFFFFFF)).mean(),
+         (raw[:, 7] >> np.uint64(32)).mean(), (raw[:, 7] & np.uint64(0xFFFFFFFF)).mean()))
