@@ -12,6 +12,9 @@
 #include <string.h>
 #include <new>
 
+#define LA_MAX_SLICES 8
+#define LA_PROF_MAX_RANGES 64
+
 struct la_gpu_ctx {
 	int device;
 	hipStream_t own_stream;
@@ -19,27 +22,34 @@ struct la_gpu_ctx {
 	hipEvent_t ev0, ev1;
 	void *ws;
 	uint64_t ws_bytes;
-	/* optional per-phase timing of the last batch (HIP events on the work stream) */
+	/* second stream + events: block checksums / parse of later slices run beside the
+	 * expand kernels of earlier ones */
+	hipStream_t aux_stream;
+	hipEvent_t slice_ev[LA_MAX_SLICES + 1];
+	/* optional timing of the last batch: one (start, stop) event pair per kernel range,
+	 * recorded on the stream the kernels run on, summed by name when read */
 	int prof_on;
 	int prof_n;
-	hipEvent_t prof_ev[LA_PROF_MAX_PHASES + 1];
-	const char *prof_name[LA_PROF_MAX_PHASES];
+	hipEvent_t prof_a[LA_PROF_MAX_RANGES], prof_b[LA_PROF_MAX_RANGES];
+	const char *prof_name[LA_PROF_MAX_RANGES];
 	char err[256];
 };
 
-static void prof_begin(la_gpu_ctx *c)
+static void prof_begin(la_gpu_ctx *c) { c->prof_n = 0; }
+/* returns a handle to close with prof_close, or -1 */
+static int prof_open(la_gpu_ctx *c, const char *name, hipStream_t s)
 {
-	c->prof_n = 0;
-	if (c->prof_on)
-		(void)hipEventRecord(c->prof_ev[0], c->stream);
+	if (!c->prof_on || c->prof_n >= LA_PROF_MAX_RANGES)
+		return -1;
+	int h = c->prof_n++;
+	c->prof_name[h] = name;
+	(void)hipEventRecord(c->prof_a[h], s);
+	return h;
 }
-static void prof_mark(la_gpu_ctx *c, const char *name)
+static void prof_close(la_gpu_ctx *c, int h, hipStream_t s)
 {
-	if (!c->prof_on || c->prof_n >= LA_PROF_MAX_PHASES)
-		return;
-	c->prof_name[c->prof_n] = name;
-	c->prof_n++;
-	(void)hipEventRecord(c->prof_ev[c->prof_n], c->stream);
+	if (h >= 0)
+		(void)hipEventRecord(c->prof_b[h], s);
 }
 
 #define HIPCHK(ctx, call)                                                              \
@@ -83,8 +93,13 @@ int la_gpu_open(int device, la_gpu_ctx **out)
 		delete c;
 		return LA_ERR_NO_DEVICE;
 	}
-	for (int i = 0; i <= LA_PROF_MAX_PHASES; i++)
-		(void)hipEventCreate(&c->prof_ev[i]);
+	for (int i = 0; i < LA_PROF_MAX_RANGES; i++) {
+		(void)hipEventCreate(&c->prof_a[i]);
+		(void)hipEventCreate(&c->prof_b[i]);
+	}
+	(void)hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
+	for (int i = 0; i <= LA_MAX_SLICES; i++)
+		(void)hipEventCreateWithFlags(&c->slice_ev[i], hipEventDisableTiming);
 	c->stream = c->own_stream;
 	*out = c;
 	return LA_OK;
@@ -99,8 +114,14 @@ void la_gpu_close(la_gpu_ctx *c)
 	if (c->ws) (void)hipFree(c->ws);
 	(void)hipEventDestroy(c->ev0);
 	(void)hipEventDestroy(c->ev1);
-	for (int i = 0; i <= LA_PROF_MAX_PHASES; i++)
-		(void)hipEventDestroy(c->prof_ev[i]);
+	for (int i = 0; i < LA_PROF_MAX_RANGES; i++) {
+		(void)hipEventDestroy(c->prof_a[i]);
+		(void)hipEventDestroy(c->prof_b[i]);
+	}
+	for (int i = 0; i <= LA_MAX_SLICES; i++)
+		(void)hipEventDestroy(c->slice_ev[i]);
+	(void)hipStreamSynchronize(c->aux_stream);
+	(void)hipStreamDestroy(c->aux_stream);
 	(void)hipStreamDestroy(c->own_stream);
 	delete c;
 }
@@ -202,11 +223,23 @@ int la_gpu_profile_read(la_gpu_ctx *c, float *ms, const char **names, int cap)
 	if (!c || !ms) return LA_ERR_ARG;
 	if (!c->prof_on || c->prof_n == 0)
 		return 0;
-	HIPCHK(c, hipEventSynchronize(c->prof_ev[c->prof_n]));
-	int n = c->prof_n < cap ? c->prof_n : cap;
-	for (int i = 0; i < n; i++) {
-		HIPCHK(c, hipEventElapsedTime(&ms[i], c->prof_ev[i], c->prof_ev[i + 1]));
-		if (names) names[i] = c->prof_name[i];
+	int n = 0;
+	for (int i = 0; i < c->prof_n; i++) {
+		float t = 0;
+		HIPCHK(c, hipEventSynchronize(c->prof_b[i]));
+		HIPCHK(c, hipEventElapsedTime(&t, c->prof_a[i], c->prof_b[i]));
+		int k = 0;
+		for (; k < n; k++)
+			if (names && names[k] == c->prof_name[i])
+				break;
+		if (k == n) {
+			if (n >= cap)
+				continue;
+			if (names) names[n] = c->prof_name[i];
+			ms[n] = 0;
+			n++;
+		}
+		ms[k] += t;
 	}
 	return n;
 }
@@ -239,14 +272,10 @@ static uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) & ~(a - 1)
 struct lz4_ws {
 	uint32_t *nseq;		/* [n] */
 	uint32_t *caps;		/* [n] table capacity per block */
-	uint32_t *lcaps;	/* [n] literal-index capacity per block */
 	uint64_t *table_off;	/* [n+1] */
-	uint64_t *lidx_off;	/* [n+1] */
 	void *scan;		/* scan scratch */
 	la_lz4_seq *table;
 	uint64_t table_cap;	/* entries */
-	uint16_t *lidx;
-	uint64_t lidx_cap;	/* entries */
 	uint64_t total;
 };
 
@@ -255,16 +284,12 @@ static void lz4_ws_layout(lz4_ws *w, uint8_t *base, uint32_t n, uint64_t src_byt
 	uint64_t o = 0;
 	w->nseq = (uint32_t *)(base + o); o += align_up((uint64_t)n * 4, 256);
 	w->caps = (uint32_t *)(base + o); o += align_up((uint64_t)n * 4, 256);
-	w->lcaps = (uint32_t *)(base + o); o += align_up((uint64_t)n * 4, 256);
 	w->table_off = (uint64_t *)(base + o); o += align_up(((uint64_t)n + 1) * 8, 256);
-	w->lidx_off = (uint64_t *)(base + o); o += align_up(((uint64_t)n + 1) * 8, 256);
 	w->scan = base + o; o += align_up(la_scan_scratch_bytes(n), 256);
-	/* a non-final sequence takes >= 3 payload bytes: sum(src_len/3 + 1) <= src_bytes/3 + n */
-	w->table_cap = with_table ? src_bytes / 3 + n : 0;
+	/* a non-final sequence takes >= 3 payload bytes; slots are rounded up to 8 entries:
+	 * sum((src_len/3 + 1 + 7) & ~7) <= src_bytes/3 + 8n */
+	w->table_cap = with_table ? src_bytes / 3 + 8ull * n : 0;
 	w->table = (la_lz4_seq *)(base + o); o += align_up(w->table_cap * sizeof(la_lz4_seq), 256);
-	/* one u16 per 16 payload bytes: sum((src_len+15)/16) <= src_bytes/16 + n */
-	w->lidx_cap = with_table ? src_bytes / 16 + n : 0;
-	w->lidx = (uint16_t *)(base + o); o += align_up(w->lidx_cap * sizeof(uint16_t), 256);
 	w->total = o + 4096;
 }
 
@@ -295,47 +320,73 @@ int la_gpu_lz4_decode(la_gpu_ctx *c, const la_lz4_batch *bt)
 		if (rc != LA_OK) return rc;
 	}
 	lz4_ws_layout(&w, (uint8_t *)c->ws, bt->n_blocks, bt->src_bytes, fast);
-	hipStream_t s = c->stream;
+	hipStream_t sx = c->stream;		/* expand / verify stream (the caller's) */
+	hipStream_t sp = c->aux_stream;		/* checksum / parse stream */
+	const uint32_t n = bt->n_blocks;
+	/* slices of blocks: parse of slice i+1 overlaps expand of slice i */
+	/* measured on MI355X: the parse kernel needs the whole table in one launch to fill the
+	 * chip (one lane per block), slicing it costs more than the overlap returns */
+	uint32_t nsl = 1u;
+	int h;
 
 	prof_begin(c);
-	if (bt->n_blocks)
-		HIPCHK(c, hipMemsetAsync(bt->d_block_status, 0, (size_t)bt->n_blocks * sizeof(uint32_t), s));
-	if (verify) {
-		la_launch_lz4_block_sums(s, bt->d_src, bt->d_blocks, bt->n_blocks, bt->d_block_status);
-		prof_mark(c, "lz4_block_sums");
-	}
+	/* the parse stream starts after whatever the caller queued on its stream */
+	HIPCHK(c, hipEventRecord(c->slice_ev[LA_MAX_SLICES], sx));
+	HIPCHK(c, hipStreamWaitEvent(sp, c->slice_ev[LA_MAX_SLICES], 0));
+	if (n)
+		HIPCHK(c, hipMemsetAsync(bt->d_block_status, 0, (size_t)n * sizeof(uint32_t), sp));
 	if (fast) {
-		la_launch_lz4_table_caps(s, bt->d_blocks, bt->n_blocks, w.caps, w.lcaps);
-		la_launch_scan_u32(s, w.caps, bt->n_blocks, w.table_off, w.scan);
-		la_launch_scan_u32(s, w.lcaps, bt->n_blocks, w.lidx_off, w.scan);
+		la_launch_lz4_table_caps(sp, bt->d_blocks, n, w.caps);
+		la_launch_scan_u32(sp, w.caps, n, w.table_off, w.scan);
 	}
-	la_launch_lz4_parse(s, bt->d_src, bt->src_bytes, bt->d_blocks, bt->n_blocks, bt->d_out_len, w.nseq,
-	    bt->d_block_status, fast ? w.table : NULL, w.table_off, w.table_cap, w.lidx, w.lidx_off, w.lidx_cap);
-	prof_mark(c, "lz4_parse");
-	la_launch_scan_u32(s, bt->d_out_len, bt->n_blocks, bt->d_dst_off, w.scan);
-	prof_mark(c, "scan");
-	if (fast) {
-		la_launch_lz4_expand_fast(s, bt->d_src, bt->src_bytes, bt->d_blocks, bt->n_blocks, bt->d_dst,
-		    bt->dst_cap, bt->d_dst_off, bt->d_out_len, bt->d_block_status, w.nseq, w.table, w.table_off,
-		    w.lidx, w.lidx_off);
-		prof_mark(c, "lz4_expand");
+	for (uint32_t i = 0; i < nsl; i++) {
+		const uint32_t first = (uint32_t)((uint64_t)n * i / nsl), cnt = (uint32_t)((uint64_t)n * (i + 1) / nsl) - first;
+		if (verify) {
+			h = prof_open(c, "lz4_block_sums", sp);
+			la_launch_lz4_block_sums(sp, bt->d_src, bt->d_blocks + first, cnt, bt->d_block_status + first);
+			prof_close(c, h, sp);
+		}
+		h = prof_open(c, "lz4_parse", sp);
+		la_launch_lz4_parse(sp, bt->d_src, bt->src_bytes, bt->d_blocks + first, cnt, bt->d_out_len + first,
+		    w.nseq + first, bt->d_block_status + first, fast ? w.table : NULL, w.table_off + first, w.table_cap);
+		prof_close(c, h, sp);
+		h = prof_open(c, "scan", sp);
+		la_launch_scan_u32_base(sp, bt->d_out_len + first, cnt, bt->d_dst_off + first, w.scan,
+		    i ? bt->d_dst_off + first : NULL);
+		prof_close(c, h, sp);
+		HIPCHK(c, hipEventRecord(c->slice_ev[i], sp));
+		if (fast) {
+			HIPCHK(c, hipStreamWaitEvent(sx, c->slice_ev[i], 0));
+			h = prof_open(c, "lz4_expand", sx);
+			la_launch_lz4_expand_fast(sx, bt->d_src, bt->src_bytes, bt->d_blocks + first, cnt, bt->d_dst,
+			    bt->dst_cap, bt->d_dst_off + first, bt->d_out_len + first, bt->d_block_status + first,
+			    w.nseq + first, w.table, w.table_off + first);
+			prof_close(c, h, sx);
+		}
 	}
-	la_launch_lz4_expand_general(s, bt->d_src, bt->src_bytes, bt->d_blocks, bt->n_blocks, bt->d_dst,
+	HIPCHK(c, hipStreamWaitEvent(sx, c->slice_ev[nsl - 1], 0));
+	/* blocks the LDS-window kernel does not take (and chains of dependent blocks, which may
+	 * cross slice boundaries) go through the general kernel once, over the whole table */
+	h = prof_open(c, fast ? "lz4_expand_general" : "lz4_expand", sx);
+	la_launch_lz4_expand_general(sx, bt->d_src, bt->src_bytes, bt->d_blocks, n, bt->d_dst,
 	    bt->dst_cap, bt->d_dst_off, bt->d_out_len, bt->d_block_status, w.nseq,
 	    fast ? LA_LZ4_FAST_MAXSEQ : 0u);
-	prof_mark(c, fast ? "lz4_expand_general" : "lz4_expand");
+	prof_close(c, h, sx);
 	if (bt->n_frames) {
+		h = prof_open(c, "lz4_frame_sums", sx);
 		if (verify)
-			la_launch_lz4_frame_sums(s, bt->d_src, bt->d_dst, bt->d_frames, bt->n_frames,
+			la_launch_lz4_frame_sums(sx, bt->d_src, bt->d_dst, bt->d_frames, bt->n_frames,
 			    bt->d_dst_off, bt->dst_cap, bt->d_frame_status);
 		else
-			HIPCHK(c, hipMemsetAsync(bt->d_frame_status, 0, (size_t)bt->n_frames * sizeof(uint32_t), s));
+			HIPCHK(c, hipMemsetAsync(bt->d_frame_status, 0, (size_t)bt->n_frames * sizeof(uint32_t), sx));
+		prof_close(c, h, sx);
 	}
-	prof_mark(c, "lz4_frame_sums");
-	if (bt->d_summary)
-		la_launch_lz4_summary(s, bt->d_out_len, bt->d_block_status, bt->n_blocks,
+	if (bt->d_summary) {
+		h = prof_open(c, "summary", sx);
+		la_launch_lz4_summary(sx, bt->d_out_len, bt->d_block_status, n,
 		    bt->d_frame_status, bt->n_frames, bt->d_dst_off, bt->d_summary);
-	prof_mark(c, "summary");
+		prof_close(c, h, sx);
+	}
 	HIPCHK(c, hipGetLastError());
 	return LA_OK;
 }
@@ -348,15 +399,16 @@ int la_gpu_gzip_decode(la_gpu_ctx *c, const la_gz_batch *bt)
 		return LA_ERR_ARG;
 	hipStream_t s = c->stream;
 	prof_begin(c);
+	int h = prof_open(c, "inflate", s);
 	la_launch_inflate(s, bt->d_src, bt->src_bytes, bt->d_members, bt->n_members, bt->d_dst, bt->dst_cap,
 	    bt->d_results);
-	prof_mark(c, "inflate");
+	prof_close(c, h, s);
+	h = prof_open(c, "gz_crc32", s);
 	la_launch_gz_verify(s, bt->d_src, bt->src_bytes, bt->d_members, bt->n_members, bt->d_dst,
 	    bt->d_results, !(bt->options & LA_GZ_OPT_NO_VERIFY));
-	prof_mark(c, "gz_crc32");
+	prof_close(c, h, s);
 	if (bt->d_summary)
 		la_launch_gz_summary(s, bt->d_results, bt->n_members, bt->d_summary);
-	prof_mark(c, "summary");
 	HIPCHK(c, hipGetLastError());
 	return LA_OK;
 }

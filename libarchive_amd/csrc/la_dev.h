@@ -235,12 +235,11 @@ __host__ __device__ __forceinline__ bool la_lz4_fast_eligible(const la_lz4_block
 	return !(b.flags & (LA_LZ4B_STORED | LA_LZ4B_DEPENDENT)) && b.dst_cap <= 65536u && b.src_len <= 65536u;
 }
 
-void la_launch_lz4_table_caps(hipStream_t s, const la_lz4_block *d_blocks, uint32_t n, uint32_t *d_caps,
-    uint32_t *d_lcaps);
+void la_launch_lz4_table_caps(hipStream_t s, const la_lz4_block *d_blocks, uint32_t n, uint32_t *d_caps);
 void la_launch_lz4_parse(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
     const la_lz4_block *d_blocks, uint32_t n, uint32_t *d_out_len, uint32_t *d_nseq,
     uint32_t *d_status, la_lz4_seq *d_table /* NULL: measure only */, const uint64_t *d_table_off,
-    uint64_t table_cap /* entries */, uint16_t *d_lidx, const uint64_t *d_lidx_off, uint64_t lidx_cap);
+    uint64_t table_cap /* entries */);
 void la_launch_lz4_expand_general(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
     const la_lz4_block *d_blocks, uint32_t n, uint8_t *d_dst, uint64_t dst_cap,
     const uint64_t *d_dst_off, const uint32_t *d_out_len, const uint32_t *d_status,
@@ -248,8 +247,7 @@ void la_launch_lz4_expand_general(hipStream_t s, const uint8_t *d_src, uint64_t 
 void la_launch_lz4_expand_fast(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
     const la_lz4_block *d_blocks, uint32_t n, uint8_t *d_dst, uint64_t dst_cap,
     const uint64_t *d_dst_off, const uint32_t *d_out_len, uint32_t *d_status,
-    const uint32_t *d_nseq, const la_lz4_seq *d_table, const uint64_t *d_table_off,
-    const uint16_t *d_lidx, const uint64_t *d_lidx_off);
+    const uint32_t *d_nseq, const la_lz4_seq *d_table, const uint64_t *d_table_off);
 
 /* la_inflate.hip */
 void la_launch_inflate(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
@@ -261,6 +259,8 @@ void la_launch_gz_summary(hipStream_t s, const la_gz_result *d_results, uint32_t
 /* la_scan.hip */
 void la_launch_scan_u32(hipStream_t s, const uint32_t *d_in, uint32_t n, uint64_t *d_out /* n+1 */,
     void *d_scratch);
+void la_launch_scan_u32_base(hipStream_t s, const uint32_t *d_in, uint32_t n, uint64_t *d_out, void *d_scratch,
+    const uint64_t *d_base);
 uint64_t la_scan_scratch_bytes(uint32_t n);
 void la_launch_lz4_summary(hipStream_t s, const uint32_t *d_out_len, const uint32_t *d_block_status,
     uint32_t n_blocks, const uint32_t *d_frame_status, uint32_t n_frames,

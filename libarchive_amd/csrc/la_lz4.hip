@@ -73,9 +73,13 @@ template <bool EMIT>
 __global__ __launch_bounds__(256) void lz4_parse_kernel(const uint8_t *__restrict__ src,
     uint64_t src_bytes, const la_lz4_block *__restrict__ blocks, uint32_t n,
     uint32_t *__restrict__ out_len, uint32_t *__restrict__ nseq_out, uint32_t *__restrict__ status,
-    la_lz4_seq *__restrict__ table, const uint64_t *__restrict__ table_off, uint64_t table_cap,
-    uint16_t *__restrict__ lit_index, const uint64_t *__restrict__ lidx_off, uint64_t lidx_cap)
+    la_lz4_seq *__restrict__ table, const uint64_t *__restrict__ table_off, uint64_t table_cap)
 {
+	/* Table entries are staged in LDS (transposed: conflict free) and leave in groups of
+	 * eight = one aligned 64-byte store burst per lane.  Single 8-byte stores from 262144
+	 * lanes to as many different cache lines exceed what L2 can hold until a line is
+	 * complete, and every partial line costs a read-modify-write in HBM. */
+	__shared__ uint64_t stage[8][256];
 	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n)
 		return;
@@ -101,16 +105,94 @@ __global__ __launch_bounds__(256) void lz4_parse_kernel(const uint8_t *__restric
 	const int dict = (b.flags & LA_LZ4B_DEPENDENT) ? 65536 : 0;	/* lz4.c:563-584: any offset reaches the zero-filled prefix */
 	/* emit only into a slot that lies inside the workspace (tables come from the host) */
 	const bool eligible = EMIT && la_lz4_fast_eligible(b);
-	const bool emit = eligible && table_off[i + 1] <= table_cap && lidx_off[i + 1] <= lidx_cap;
-	la_lz4_seq *tab = emit ? table + table_off[i] : nullptr;
-	/* lidx[c] = first sequence that still has literal bytes at or after payload offset 16*c */
-	uint16_t *lidx = emit ? lit_index + lidx_off[i] : nullptr;
-	int nchunk = 0;
+	const bool emit = eligible && table_off[i + 1] <= table_cap;
+	uint64_t *tab = emit ? (uint64_t *)(table + table_off[i]) : nullptr;	/* slot is 64-byte aligned */
+#define EMIT_SEQ(lit_src_, lit_len_, dst_, off_)                                                   \
+	do {                                                                                       \
+		stage[nseq & 7][threadIdx.x] = (uint64_t)(uint16_t)(lit_src_) |                    \
+		    ((uint64_t)(uint16_t)(lit_len_) << 16) | ((uint64_t)(uint16_t)(dst_) << 32) |  \
+		    ((uint64_t)(uint16_t)(off_) << 48);                                            \
+		if ((nseq & 7) == 7) {                                                             \
+			uint4 *o4 = (uint4 *)(tab + (nseq - 7));                                   \
+			for (int j_ = 0; j_ < 4; j_++) {                                           \
+				uint64_t a_ = stage[2 * j_][threadIdx.x], b_ = stage[2 * j_ + 1][threadIdx.x]; \
+				o4[j_] = make_uint4((uint32_t)a_, (uint32_t)(a_ >> 32), (uint32_t)b_, (uint32_t)(b_ >> 32)); \
+			}                                                                          \
+		}                                                                                  \
+	} while (0)
 	int ip = 0, op = 0;
 	uint32_t nseq = 0;
 	bool ok = iend > 0;
 
-	while (ok) {
+	/* Blocks whose payload ends at least 8 bytes before the end of the image (all but the
+	 * last one or two of a stream) take the lean loop: one unchecked 8-byte load at the
+	 * token, a second one at the offset only when the literal run pushes it out of the
+	 * first, length extensions (rare) through the careful byte reader.  Same rules, same
+	 * results as the careful loop below. */
+	const bool lean = (int64_t)iend + 8 <= room;
+	while (ok && lean) {
+		uint64_t w;
+		__builtin_memcpy(&w, B.s + ip, 8);
+		const uint32_t token = (uint32_t)w & 0xffu;
+		int length = (int)(token >> 4);
+		int hdr = 1;			/* bytes of w consumed so far */
+		ip++;
+		if (length == 15) {
+			if (ip >= iend - 15) { ok = false; break; }
+			uint32_t x;
+			do {
+				x = bw_get(B, ip++);
+				length += (int)x;
+				if (ip >= iend - 15)
+					break;
+			} while (x == 255);
+			hdr = 9;		/* the offset is not in w any more */
+		}
+		if (op + length > oend - LZ4_MFLIMIT || ip + length > iend - (2 + 1 + LZ4_LASTLIT)) {
+			if (ip + length != iend || op + length > oend)
+				ok = false;
+			else if (emit && length > 0) {
+				EMIT_SEQ(ip, length, op, 0);
+				nseq++;
+			}
+			op += length;
+			break;
+		}
+		const int lit_src = ip, lit_len = length, lit_dst = op;
+		ip += length;
+		op += length;
+		/* offset (2 bytes) + first match-length extension byte */
+		uint32_t o3;
+		if (hdr + length + 3 <= 8)
+			o3 = (uint32_t)(w >> (8 * (hdr + length)));
+		else {
+			uint64_t w2;
+			__builtin_memcpy(&w2, B.s + ip, 8);
+			o3 = (uint32_t)w2;
+		}
+		const int offset = (int)(o3 & 0xffffu);
+		ip += 2;
+		length = (int)(token & 15);
+		if (length == 15) {
+			uint32_t x = (o3 >> 16) & 0xffu;	/* first extension byte came with the offset */
+			ip++;
+			length += (int)x;
+			if (ip >= iend - LZ4_LASTLIT + 1) { ok = false; break; }
+			while (x == 255) {
+				x = bw_get(B, ip++);
+				length += (int)x;
+				if (ip >= iend - LZ4_LASTLIT + 1) { ok = false; break; }
+			}
+			if (!ok) break;
+		}
+		length += 4;
+		if (offset == 0 || offset > op + dict || op + length > oend - LZ4_LASTLIT) { ok = false; break; }
+		if (emit)
+			EMIT_SEQ(lit_src, lit_len, lit_dst, offset);
+		nseq++;
+		op += length;
+	}
+	while (ok && !lean) {
 		uint32_t token = bw_get(B, ip++);
 		int length = (int)(token >> 4);
 		if (length == 15) {
@@ -127,10 +209,7 @@ __global__ __launch_bounds__(256) void lz4_parse_kernel(const uint8_t *__restric
 			if (ip + length != iend || op + length > oend)
 				ok = false;
 			else if (emit && length > 0) {
-				la_lz4_seq e = { (uint16_t)ip, (uint16_t)length, (uint16_t)op, 0 };
-				tab[nseq] = e;
-				for (; 16 * nchunk < ip + length; nchunk++)
-					lidx[nchunk] = (uint16_t)nseq;
+				EMIT_SEQ(ip, length, op, 0);
 				nseq++;
 			}
 			op += length;
@@ -153,18 +232,15 @@ __global__ __launch_bounds__(256) void lz4_parse_kernel(const uint8_t *__restric
 		}
 		length += 4;
 		if (offset == 0 || offset > op + dict || op + length > oend - LZ4_LASTLIT) { ok = false; break; }
-		if (emit) {
-			la_lz4_seq e = { (uint16_t)lit_src, (uint16_t)lit_len, (uint16_t)lit_dst, (uint16_t)offset };
-			tab[nseq] = e;
-			for (; 16 * nchunk < lit_src + lit_len; nchunk++)
-				lidx[nchunk] = (uint16_t)nseq;
-		}
+		if (emit)
+			EMIT_SEQ(lit_src, lit_len, lit_dst, offset);
 		nseq++;
 		op += length;
 	}
 	if (emit && ok)
-		for (; 16 * nchunk < iend; nchunk++)
-			lidx[nchunk] = (uint16_t)nseq;	/* no literals from here on */
+		for (uint32_t j = nseq & ~7u; j < nseq; j++)	/* the last, incomplete group of eight */
+			tab[j] = stage[j & 7][threadIdx.x];
+#undef EMIT_SEQ
 	out_len[i] = ok ? (uint32_t)op : 0u;
 	/* an eligible block without a table slot must go to the general kernel */
 	nseq_out[i] = ok ? ((eligible && !emit) ? 0xFFFFFFFFu : nseq) : 0u;
@@ -174,37 +250,32 @@ __global__ __launch_bounds__(256) void lz4_parse_kernel(const uint8_t *__restric
 
 /* table capacity per block: a non-final sequence takes at least 3 payload bytes */
 __global__ __launch_bounds__(256) void lz4_table_caps_kernel(const la_lz4_block *__restrict__ blocks,
-    uint32_t n, uint32_t *__restrict__ caps, uint32_t *__restrict__ lcaps)
+    uint32_t n, uint32_t *__restrict__ caps)
 {
 	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n)
 		return;
 	la_lz4_block b = blocks[i];
-	caps[i] = la_lz4_fast_eligible(b) ? b.src_len / 3 + 1 : 0u;
-	lcaps[i] = la_lz4_fast_eligible(b) ? (b.src_len + 15) / 16 : 0u;
+	caps[i] = la_lz4_fast_eligible(b) ? (b.src_len / 3 + 1 + 7) & ~7u : 0u;	/* slots stay 64-byte aligned */
 }
 
-void la_launch_lz4_table_caps(hipStream_t s, const la_lz4_block *d_blocks, uint32_t n, uint32_t *d_caps,
-    uint32_t *d_lcaps)
+void la_launch_lz4_table_caps(hipStream_t s, const la_lz4_block *d_blocks, uint32_t n, uint32_t *d_caps)
 {
 	if (n == 0) return;
-	hipLaunchKernelGGL(lz4_table_caps_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_blocks, n, d_caps, d_lcaps);
+	hipLaunchKernelGGL(lz4_table_caps_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_blocks, n, d_caps);
 }
 
 void la_launch_lz4_parse(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
     const la_lz4_block *d_blocks, uint32_t n, uint32_t *d_out_len, uint32_t *d_nseq,
-    uint32_t *d_status, la_lz4_seq *d_table, const uint64_t *d_table_off, uint64_t table_cap,
-    uint16_t *d_lidx, const uint64_t *d_lidx_off, uint64_t lidx_cap)
+    uint32_t *d_status, la_lz4_seq *d_table, const uint64_t *d_table_off, uint64_t table_cap)
 {
 	if (n == 0) return;
 	if (d_table)
 		hipLaunchKernelGGL(lz4_parse_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, s,
-		    d_src, src_bytes, d_blocks, n, d_out_len, d_nseq, d_status, d_table, d_table_off, table_cap,
-		    d_lidx, d_lidx_off, lidx_cap);
+		    d_src, src_bytes, d_blocks, n, d_out_len, d_nseq, d_status, d_table, d_table_off, table_cap);
 	else
 		hipLaunchKernelGGL(lz4_parse_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, s,
-		    d_src, src_bytes, d_blocks, n, d_out_len, d_nseq, d_status, d_table, d_table_off, table_cap,
-		    d_lidx, d_lidx_off, lidx_cap);
+		    d_src, src_bytes, d_blocks, n, d_out_len, d_nseq, d_status, d_table, d_table_off, table_cap);
 }
 
 /* ------------------------------------------------------------------ general expand */

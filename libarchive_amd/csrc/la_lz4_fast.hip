@@ -34,6 +34,9 @@
  */
 #include "la_dev.h"
 
+#ifndef POLL_SLEEP
+#define POLL_SLEEP 1
+#endif
 #define FAST_THREADS 512
 #define FAST_WAVES   (FAST_THREADS / 64)
 
@@ -114,13 +117,13 @@ __global__ __launch_bounds__(FAST_THREADS, 4) void lz4_expand_fast_kernel(
     uint32_t n, uint8_t *__restrict__ dst, uint64_t dst_cap, const uint64_t *__restrict__ dst_off,
     const uint32_t *__restrict__ out_len, uint32_t *status_out,
     const uint32_t *__restrict__ nseq, const la_lz4_seq *__restrict__ table,
-    const uint64_t *__restrict__ table_off, const uint16_t *__restrict__ lit_index,
-    const uint64_t *__restrict__ lidx_off)
+    const uint64_t *__restrict__ table_off)
 {
 	const uint32_t *status = status_out;
 	__shared__ __attribute__((aligned(16))) uint8_t win[65536 + 32];
 	__shared__ uint16_t dstpos[MAXSEQ + 4];
 	__shared__ uint32_t donebits[MAXSEQ / 32];	/* one bit per sequence: its match is in the window */
+	__shared__ uint16_t chunk_first[2048 + 8];	/* per 32-byte payload chunk: first sequence with literals in or after it */
 
 	const uint32_t bi = blockIdx.x;
 	if (bi >= n)
@@ -137,99 +140,110 @@ __global__ __launch_bounds__(FAST_THREADS, 4) void lz4_expand_fast_kernel(
 	STAMP(0);
 	const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const la_lz4_seq *tab = table + table_off[bi];
-	const uint16_t *lidx = lit_index + lidx_off[bi];
 	const uint8_t *s = src + b.src_off;
 	const uint64_t s_room = src_bytes - b.src_off;	/* bytes of the image from s on */
 	uint8_t *g_out = dst + doff;
 	uint8_t *W = win + ((uintptr_t)g_out & 15);	/* W[i] <-> g_out[i], congruent mod 16 */
 
-	/* This thread's sequences k = (r*8 + wave)*64 + lane, r = 0..MAXSTEPS-1: their table
-	 * entries are fetched once, up front, and stay in registers for both passes over
-	 * them (output positions -> LDS now, matches later). */
+	/* This thread's sequences (fast_seq_index): their table entries are fetched once, up
+	 * front, and stay in registers for every pass over them.  The entry of the sequence
+	 * before each one comes along: its literal end tells which payload chunks START their
+	 * literals with this sequence. */
 	constexpr uint32_t MAXSTEPS = MAXSEQ / FAST_THREADS;
 	seq_t ent[MAXSTEPS];
+	uint32_t prev_end[MAXSTEPS];
 #pragma unroll
 	for (uint32_t r = 0; r < MAXSTEPS; r++) {
 		const uint32_t k = fast_seq_index(r, wave, lane);
 		ent[r] = k < ns ? seq_load(tab, k) : 0;
+		const seq_t pv = (k > 0 && k < ns) ? seq_load(tab, k - 1) : 0;
+		prev_end[r] = SEQ_LIT_SRC(pv) + SEQ_LIT_LEN(pv);
 	}
 	if (tid < MAXSEQ / 32)
 		donebits[tid] = 0;
-
-	/* ---- phase L: literals, one thread per 16-byte payload chunk ----
-	 * Four chunks per thread are in flight at a time: their payload and index loads
-	 * are issued together, then their table entries, then the byte scatter. */
-	const uint32_t nchunks = (b.src_len + 15) >> 4;
-	for (uint32_t base = 0; base < nchunks; base += 4 * FAST_THREADS) {
-		uint32_t kk[4];
-		uint4 vv[4];
+	/* chunk_first[c] = first sequence whose literals end beyond payload offset 32c */
 #pragma unroll
-		for (int u = 0; u < 4; u++) {
+	for (uint32_t r = 0; r < MAXSTEPS; r++) {
+		const uint32_t k = fast_seq_index(r, wave, lane);
+		if (k < ns) {
+			const uint32_t le = SEQ_LIT_SRC(ent[r]) + SEQ_LIT_LEN(ent[r]);
+			for (uint32_t c = (prev_end[r] + 31) >> 5; (c << 5) < le; c++)
+				chunk_first[c] = (uint16_t)k;
+			dstpos[k] = (uint16_t)SEQ_DST(ent[r]);
+			if (k + 1 == ns)
+				chunk_first[2048] = (uint16_t)((le + 31) >> 5);	/* chunks from here on hold no literals */
+		}
+	}
+	__syncthreads();
+
+	/* ---- phase L: literals, one thread per 32-byte payload chunk ----
+	 * Two coalesced 16-byte loads of the compressed stream per chunk; the chunk's
+	 * sequences come from chunk_first (LDS) and six table entries fetched together;
+	 * literal bytes go to the window with unaligned 8-byte LDS stores.  Work is balanced
+	 * by payload bytes, and every payload byte is read once. */
+	const uint32_t nlit_chunks = chunk_first[2048];
+	for (uint32_t base = 0; base < nlit_chunks; base += 2 * FAST_THREADS) {
+		uint32_t kk[2];
+		uint64_t vv[2][4];
+		seq_t pe[2][6];
+#pragma unroll
+		for (int u = 0; u < 2; u++) {
 			const uint32_t c = base + u * FAST_THREADS + tid;
 			kk[u] = 0xFFFFFFFFu;
-			vv[u] = make_uint4(0, 0, 0, 0);
-			if (c < nchunks) {
-				kk[u] = lidx[c];
-				const uint32_t c0 = c << 4;
-				if ((uint64_t)c0 + 16 <= s_room)
-					vv[u] = ld_u128(s + c0);
-				else {
+			vv[u][0] = vv[u][1] = vv[u][2] = vv[u][3] = 0;
+			if (c < nlit_chunks) {
+				kk[u] = chunk_first[c];
+				const uint32_t c0 = c << 5;
+				if ((uint64_t)c0 + 32 <= s_room) {
+					const uint4 a = ld_u128(s + c0), bq = ld_u128(s + c0 + 16);
+					vv[u][0] = ((uint64_t)a.y << 32) | a.x; vv[u][1] = ((uint64_t)a.w << 32) | a.z;
+					vv[u][2] = ((uint64_t)bq.y << 32) | bq.x; vv[u][3] = ((uint64_t)bq.w << 32) | bq.z;
+				} else {
 					/* last chunk of the image: never read past it */
-					uint64_t lo8 = 0, hi8 = 0;
-					for (uint32_t i = 0; c0 + i < s_room && i < 8; i++)
-						lo8 |= (uint64_t)s[c0 + i] << (8 * i);
-					for (uint32_t i = 8; c0 + i < s_room && i < 16; i++)
-						hi8 |= (uint64_t)s[c0 + i] << (8 * (i - 8));
-					vv[u] = make_uint4((uint32_t)lo8, (uint32_t)(lo8 >> 32), (uint32_t)hi8, (uint32_t)(hi8 >> 32));
+					for (uint32_t i = 0; c0 + i < s_room && i < 32; i++) {
+						const uint64_t by = (uint64_t)s[c0 + i] << (8 * (i & 7));
+						if (i < 8) vv[u][0] |= by; else if (i < 16) vv[u][1] |= by;
+						else if (i < 24) vv[u][2] |= by; else vv[u][3] |= by;
+					}
 				}
 			}
 		}
-		seq_t pe[4][4];
 #pragma unroll
-		for (int u = 0; u < 4; u++) {
+		for (int u = 0; u < 2; u++) {
 #pragma unroll
-			for (int t = 0; t < 4; t++)
+			for (int t = 0; t < 6; t++)
 				pe[u][t] = (kk[u] != 0xFFFFFFFFu && kk[u] + t < ns) ? seq_load(tab, kk[u] + t) : 0;
 		}
 #pragma unroll
-		for (int u = 0; u < 4; u++) {
+		for (int u = 0; u < 2; u++) {
 			if (kk[u] == 0xFFFFFFFFu)
 				continue;
-			const uint32_t c0 = (base + u * FAST_THREADS + tid) << 4, c1 = c0 + 16;
-			const uint4 v = vv[u];
+			const uint32_t c0 = (base + u * FAST_THREADS + tid) << 5, c1 = c0 + 32;
 			uint32_t k = kk[u];
 			for (uint32_t it = 0; k < ns; it++, k++) {
-				const seq_t e = it == 0 ? pe[u][0] : it == 1 ? pe[u][1] : it == 2 ? pe[u][2] : it == 3 ? pe[u][3] : seq_load(tab, k);
+				const seq_t e = it == 0 ? pe[u][0] : it == 1 ? pe[u][1] : it == 2 ? pe[u][2] :
+				    it == 3 ? pe[u][3] : it == 4 ? pe[u][4] : it == 5 ? pe[u][5] : seq_load(tab, k);
 				const uint32_t ls = SEQ_LIT_SRC(e), le = ls + SEQ_LIT_LEN(e);
 				if (ls >= c1)
 					break;
 				const uint32_t lo = ls > c0 ? ls : c0, hi = le < c1 ? le : c1;
-				if (hi > lo) {
-					/* bytes [lo-c0, hi-c0) of the 16-byte register chunk -> window */
-					const uint32_t i = lo - c0, nb = hi - lo;
-					const uint64_t vlo = ((uint64_t)v.y << 32) | v.x, vhi = ((uint64_t)v.w << 32) | v.z;
-					uint64_t a, bq;	/* chunk shifted right by i bytes: a = low 8 bytes, bq = next 8 */
-					if (i >= 8) { a = vhi >> (8 * (i - 8)); bq = 0; }
-					else if (i == 0) { a = vlo; bq = vhi; }
-					else { a = (vlo >> (8 * i)) | (vhi << (64 - 8 * i)); bq = vhi >> (8 * i); }
-					uint8_t *wp = W + SEQ_DST(e) + (lo - ls);
-					if (nb >= 8) {
-						lds_st8(wp, a);
-						if (nb == 16) lds_st8(wp + 8, bq);
-						else lds_st_tail(wp + 8, bq, nb - 8);
-					} else
-						lds_st_tail(wp, a, nb);
+				uint8_t *wp = W + SEQ_DST(e) + (lo - ls);
+				/* bytes [lo-c0, hi-c0) of the 32-byte register chunk -> window, 8 at a time */
+				for (uint32_t p0 = lo; p0 < hi; p0 += 8, wp += 8) {
+					const uint32_t i = p0 - c0, q = i >> 3, sh = (i & 7) * 8;
+					const uint64_t w0 = q == 0 ? vv[u][0] : q == 1 ? vv[u][1] : q == 2 ? vv[u][2] : vv[u][3];
+					const uint64_t w1 = q == 0 ? vv[u][1] : q == 1 ? vv[u][2] : q == 2 ? vv[u][3] : 0;
+					const uint64_t val = sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
+					const uint32_t nb = hi - p0;
+					if (nb >= 8)
+						lds_st8(wp, val);
+					else
+						lds_st_tail(wp, val, nb);
 				}
 				if (le >= c1)
 					break;
 			}
 		}
-	}
-#pragma unroll
-	for (uint32_t r = 0; r < MAXSTEPS; r++) {
-		const uint32_t k = fast_seq_index(r, wave, lane);
-		if (k < ns)
-			dstpos[k] = (uint16_t)SEQ_DST(ent[r]);
 	}
 	STAMP(1);
 	__syncthreads();
@@ -372,7 +386,7 @@ __global__ __launch_bounds__(FAST_THREADS, 4) void lz4_expand_fast_kernel(
 			}
 			if (__ballot(!fin) == 0)
 				break;
-			__builtin_amdgcn_s_sleep(2);	/* back off: polling waves share the LDS with copying ones */
+			__builtin_amdgcn_s_sleep(POLL_SLEEP);	/* back off: polling waves share the LDS with copying ones */
 		}
 	}
 	STAMP(3);
@@ -406,11 +420,10 @@ extern "C" int la_diag_set_stamps(void *d_buf)
 void la_launch_lz4_expand_fast(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
     const la_lz4_block *d_blocks, uint32_t n, uint8_t *d_dst, uint64_t dst_cap,
     const uint64_t *d_dst_off, const uint32_t *d_out_len, uint32_t *d_status,
-    const uint32_t *d_nseq, const la_lz4_seq *d_table, const uint64_t *d_table_off,
-    const uint16_t *d_lidx, const uint64_t *d_lidx_off)
+    const uint32_t *d_nseq, const la_lz4_seq *d_table, const uint64_t *d_table_off)
 {
 	if (n == 0) return;
 	hipLaunchKernelGGL(lz4_expand_fast_kernel<LA_LZ4_FAST_MAXSEQ>, dim3(n), dim3(FAST_THREADS), 0, s,
 	    d_src, src_bytes, d_blocks, n, d_dst, dst_cap, d_dst_off, d_out_len, d_status, d_nseq,
-	    d_table, d_table_off, d_lidx, d_lidx_off);
+	    d_table, d_table_off);
 }

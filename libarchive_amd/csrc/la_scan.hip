@@ -63,8 +63,10 @@ __global__ __launch_bounds__(SCAN_TPB) void scan_tile_offsets(uint64_t *tile_sum
 }
 
 __global__ __launch_bounds__(SCAN_TPB) void scan_write(const uint32_t *__restrict__ in, uint32_t n,
-    const uint64_t *__restrict__ tile_offs, uint64_t *__restrict__ out)
+    const uint64_t *__restrict__ tile_offs, uint64_t *out, const uint64_t *base_ptr)
 {
+	/* base_ptr may alias out[0] (a slice continuing the previous slice's scan): read it first */
+	const uint64_t base0 = base_ptr ? *base_ptr : 0;
 	uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
 	uint32_t v[SCAN_ITEMS];
 	uint64_t s = 0;
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(SCAN_TPB) void scan_write(const uint32_t *__restric
 		s += v[k];
 	}
 	uint64_t tot;
-	uint64_t ex = block_excl_scan(s, &tot) + tile_offs[blockIdx.x];
+	uint64_t ex = block_excl_scan(s, &tot) + tile_offs[blockIdx.x] + base0;
 	for (int k = 0; k < SCAN_ITEMS; k++) {
 		if (base + k < n) out[base + k] = ex;
 		ex += v[k];
@@ -88,15 +90,25 @@ uint64_t la_scan_scratch_bytes(uint32_t n)
 
 void la_launch_scan_u32(hipStream_t s, const uint32_t *d_in, uint32_t n, uint64_t *d_out, void *d_scratch)
 {
+	la_launch_scan_u32_base(s, d_in, n, d_out, d_scratch, NULL);
+}
+
+/* d_base: device pointer to the value the scan starts from (NULL = 0); may be d_out itself */
+void la_launch_scan_u32_base(hipStream_t s, const uint32_t *d_in, uint32_t n, uint64_t *d_out, void *d_scratch,
+    const uint64_t *d_base)
+{
 	if (n == 0) {
-		hipMemsetAsync(d_out, 0, sizeof(uint64_t), s);
+		if (!d_base)
+			(void)hipMemsetAsync(d_out, 0, sizeof(uint64_t), s);
+		else if (d_base != d_out)
+			(void)hipMemcpyAsync(d_out, d_base, sizeof(uint64_t), hipMemcpyDeviceToDevice, s);
 		return;
 	}
 	uint32_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
 	uint64_t *tiles = (uint64_t *)d_scratch;
 	hipLaunchKernelGGL(scan_tile_sums, dim3(ntiles), dim3(SCAN_TPB), 0, s, d_in, n, tiles);
 	hipLaunchKernelGGL(scan_tile_offsets, dim3(1), dim3(SCAN_TPB), 0, s, tiles, ntiles);
-	hipLaunchKernelGGL(scan_write, dim3(ntiles), dim3(SCAN_TPB), 0, s, d_in, n, tiles, d_out);
+	hipLaunchKernelGGL(scan_write, dim3(ntiles), dim3(SCAN_TPB), 0, s, d_in, n, tiles, d_out, d_base);
 }
 
 /* ------------------------------------------------------------------ summary */
