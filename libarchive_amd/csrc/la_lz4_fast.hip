@@ -150,6 +150,28 @@ __global__ __launch_bounds__(FAST_THREADS, 4) void lz4_expand_fast_kernel(
 	 * before each one comes along: its literal end tells which payload chunks START their
 	 * literals with this sequence. */
 	constexpr uint32_t MAXSTEPS = MAXSEQ / FAST_THREADS;
+	/* the first two payload chunks of this thread (phase L) are requested right away:
+	 * they depend on nothing, and their latency overlaps the table prepass */
+	uint64_t vv[2][4];
+#pragma unroll
+	for (int u = 0; u < 2; u++) {
+		const uint32_t c0 = (u * FAST_THREADS + tid) << 5;
+		vv[u][0] = vv[u][1] = vv[u][2] = vv[u][3] = 0;
+		if (c0 < b.src_len) {
+			if ((uint64_t)c0 + 32 <= s_room) {
+				const uint4 a = ld_u128(s + c0), bq = ld_u128(s + c0 + 16);
+				vv[u][0] = ((uint64_t)a.y << 32) | a.x; vv[u][1] = ((uint64_t)a.w << 32) | a.z;
+				vv[u][2] = ((uint64_t)bq.y << 32) | bq.x; vv[u][3] = ((uint64_t)bq.w << 32) | bq.z;
+			} else {
+				/* last chunk of the image: never read past it */
+				for (uint32_t i = 0; c0 + i < s_room && i < 32; i++) {
+					const uint64_t by = (uint64_t)s[c0 + i] << (8 * (i & 7));
+					if (i < 8) vv[u][0] |= by; else if (i < 16) vv[u][1] |= by;
+					else if (i < 24) vv[u][2] |= by; else vv[u][3] |= by;
+				}
+			}
+		}
+	}
 	seq_t ent[MAXSTEPS];
 	uint32_t prev_end[MAXSTEPS];
 #pragma unroll
@@ -184,26 +206,25 @@ __global__ __launch_bounds__(FAST_THREADS, 4) void lz4_expand_fast_kernel(
 	const uint32_t nlit_chunks = chunk_first[2048];
 	for (uint32_t base = 0; base < nlit_chunks; base += 2 * FAST_THREADS) {
 		uint32_t kk[2];
-		uint64_t vv[2][4];
 		seq_t pe[2][6];
 #pragma unroll
 		for (int u = 0; u < 2; u++) {
 			const uint32_t c = base + u * FAST_THREADS + tid;
-			kk[u] = 0xFFFFFFFFu;
-			vv[u][0] = vv[u][1] = vv[u][2] = vv[u][3] = 0;
-			if (c < nlit_chunks) {
-				kk[u] = chunk_first[c];
+			kk[u] = c < nlit_chunks ? (uint32_t)chunk_first[c] : 0xFFFFFFFFu;
+			if (base != 0) {	/* payloads beyond 32 KiB: later chunks are loaded here */
+				vv[u][0] = vv[u][1] = vv[u][2] = vv[u][3] = 0;
 				const uint32_t c0 = c << 5;
-				if ((uint64_t)c0 + 32 <= s_room) {
-					const uint4 a = ld_u128(s + c0), bq = ld_u128(s + c0 + 16);
-					vv[u][0] = ((uint64_t)a.y << 32) | a.x; vv[u][1] = ((uint64_t)a.w << 32) | a.z;
-					vv[u][2] = ((uint64_t)bq.y << 32) | bq.x; vv[u][3] = ((uint64_t)bq.w << 32) | bq.z;
-				} else {
-					/* last chunk of the image: never read past it */
-					for (uint32_t i = 0; c0 + i < s_room && i < 32; i++) {
-						const uint64_t by = (uint64_t)s[c0 + i] << (8 * (i & 7));
-						if (i < 8) vv[u][0] |= by; else if (i < 16) vv[u][1] |= by;
-						else if (i < 24) vv[u][2] |= by; else vv[u][3] |= by;
+				if (c < nlit_chunks) {
+					if ((uint64_t)c0 + 32 <= s_room) {
+						const uint4 a = ld_u128(s + c0), bq = ld_u128(s + c0 + 16);
+						vv[u][0] = ((uint64_t)a.y << 32) | a.x; vv[u][1] = ((uint64_t)a.w << 32) | a.z;
+						vv[u][2] = ((uint64_t)bq.y << 32) | bq.x; vv[u][3] = ((uint64_t)bq.w << 32) | bq.z;
+					} else {
+						for (uint32_t i = 0; c0 + i < s_room && i < 32; i++) {
+							const uint64_t by = (uint64_t)s[c0 + i] << (8 * (i & 7));
+							if (i < 8) vv[u][0] |= by; else if (i < 16) vv[u][1] |= by;
+							else if (i < 24) vv[u][2] |= by; else vv[u][3] |= by;
+						}
 					}
 				}
 			}
