@@ -272,6 +272,7 @@ static uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) & ~(a - 1)
 struct lz4_ws {
 	uint32_t *nseq;		/* [n] */
 	uint32_t *caps;		/* [n] table capacity per block */
+	uint32_t *sum_status;	/* [n] block-checksum verdicts (merged into the status at the end) */
 	uint64_t *table_off;	/* [n+1] */
 	void *scan;		/* scan scratch */
 	la_lz4_seq *table;
@@ -284,6 +285,7 @@ static void lz4_ws_layout(lz4_ws *w, uint8_t *base, uint32_t n, uint64_t src_byt
 	uint64_t o = 0;
 	w->nseq = (uint32_t *)(base + o); o += align_up((uint64_t)n * 4, 256);
 	w->caps = (uint32_t *)(base + o); o += align_up((uint64_t)n * 4, 256);
+	w->sum_status = (uint32_t *)(base + o); o += align_up((uint64_t)n * 4, 256);
 	w->table_off = (uint64_t *)(base + o); o += align_up(((uint64_t)n + 1) * 8, 256);
 	w->scan = base + o; o += align_up(la_scan_scratch_bytes(n), 256);
 	/* a non-final sequence takes >= 3 payload bytes; slots are rounded up to 8 entries:
@@ -320,67 +322,79 @@ int la_gpu_lz4_decode(la_gpu_ctx *c, const la_lz4_batch *bt)
 		if (rc != LA_OK) return rc;
 	}
 	lz4_ws_layout(&w, (uint8_t *)c->ws, bt->n_blocks, bt->src_bytes, fast);
-	hipStream_t sx = c->stream;		/* expand / verify stream (the caller's) */
-	hipStream_t sp = c->aux_stream;		/* checksum / parse stream */
+	hipStream_t sx = c->stream;		/* main stream (the caller's): checksums, expand, summary */
+	hipStream_t sp = c->aux_stream;		/* second stream: parse beside the block checksums, frame
+						 * checksums beside the expand kernel */
 	const uint32_t n = bt->n_blocks;
-	/* slices of blocks: parse of slice i+1 overlaps expand of slice i */
-	/* measured on MI355X: the parse kernel needs the whole table in one launch to fill the
-	 * chip (one lane per block), slicing it costs more than the overlap returns */
-	uint32_t nsl = 1u;
 	int h;
 
 	prof_begin(c);
-	/* the parse stream starts after whatever the caller queued on its stream */
+	/* the second stream starts after whatever the caller queued on its stream */
 	HIPCHK(c, hipEventRecord(c->slice_ev[LA_MAX_SLICES], sx));
 	HIPCHK(c, hipStreamWaitEvent(sp, c->slice_ev[LA_MAX_SLICES], 0));
+
+	/* second stream: token-chain parse (+ sequence tables) of the whole batch.  One lane per
+	 * block: it needs the whole table in one launch to fill the chip. */
 	if (n)
 		HIPCHK(c, hipMemsetAsync(bt->d_block_status, 0, (size_t)n * sizeof(uint32_t), sp));
 	if (fast) {
 		la_launch_lz4_table_caps(sp, bt->d_blocks, n, w.caps);
 		la_launch_scan_u32(sp, w.caps, n, w.table_off, w.scan);
 	}
-	for (uint32_t i = 0; i < nsl; i++) {
-		const uint32_t first = (uint32_t)((uint64_t)n * i / nsl), cnt = (uint32_t)((uint64_t)n * (i + 1) / nsl) - first;
-		if (verify) {
-			h = prof_open(c, "lz4_block_sums", sp);
-			la_launch_lz4_block_sums(sp, bt->d_src, bt->d_blocks + first, cnt, bt->d_block_status + first);
-			prof_close(c, h, sp);
-		}
-		h = prof_open(c, "lz4_parse", sp);
-		la_launch_lz4_parse(sp, bt->d_src, bt->src_bytes, bt->d_blocks + first, cnt, bt->d_out_len + first,
-		    w.nseq + first, bt->d_block_status + first, fast ? w.table : NULL, w.table_off + first, w.table_cap);
+	/* block checksums into their own verdict array, then the parse (measured: running the two
+	 * side by side on two streams is slower than back to back) */
+	if (verify && n) {
+		HIPCHK(c, hipMemsetAsync(w.sum_status, 0, (size_t)n * sizeof(uint32_t), sp));
+		h = prof_open(c, "lz4_block_sums", sp);
+		la_launch_lz4_block_sums(sp, bt->d_src, bt->d_blocks, n, w.sum_status);
 		prof_close(c, h, sp);
-		h = prof_open(c, "scan", sp);
-		la_launch_scan_u32_base(sp, bt->d_out_len + first, cnt, bt->d_dst_off + first, w.scan,
-		    i ? bt->d_dst_off + first : NULL);
-		prof_close(c, h, sp);
-		HIPCHK(c, hipEventRecord(c->slice_ev[i], sp));
-		if (fast) {
-			HIPCHK(c, hipStreamWaitEvent(sx, c->slice_ev[i], 0));
-			h = prof_open(c, "lz4_expand", sx);
-			la_launch_lz4_expand_fast(sx, bt->d_src, bt->src_bytes, bt->d_blocks + first, cnt, bt->d_dst,
-			    bt->dst_cap, bt->d_dst_off + first, bt->d_out_len + first, bt->d_block_status + first,
-			    w.nseq + first, w.table, w.table_off + first);
-			prof_close(c, h, sx);
-		}
 	}
-	HIPCHK(c, hipStreamWaitEvent(sx, c->slice_ev[nsl - 1], 0));
-	/* blocks the LDS-window kernel does not take (and chains of dependent blocks, which may
-	 * cross slice boundaries) go through the general kernel once, over the whole table */
+	h = prof_open(c, "lz4_parse", sp);
+	la_launch_lz4_parse(sp, bt->d_src, bt->src_bytes, bt->d_blocks, n, bt->d_out_len, w.nseq,
+	    bt->d_block_status, fast ? w.table : NULL, w.table_off, w.table_cap);
+	prof_close(c, h, sp);
+	HIPCHK(c, hipEventRecord(c->slice_ev[0], sp));
+
+	HIPCHK(c, hipStreamWaitEvent(sx, c->slice_ev[0], 0));
+	h = prof_open(c, "scan", sx);
+	la_launch_scan_u32(sx, bt->d_out_len, n, bt->d_dst_off, w.scan);
+	prof_close(c, h, sx);
+
+	/* blocks the LDS-window kernel does not take (any size, stored, chains of dependent
+	 * blocks) first, over the whole table; then the LDS-window kernel in slices, each
+	 * slice's frames hashed on the second stream while the next slice expands */
 	h = prof_open(c, fast ? "lz4_expand_general" : "lz4_expand", sx);
 	la_launch_lz4_expand_general(sx, bt->d_src, bt->src_bytes, bt->d_blocks, n, bt->d_dst,
 	    bt->dst_cap, bt->d_dst_off, bt->d_out_len, bt->d_block_status, w.nseq,
 	    fast ? LA_LZ4_FAST_MAXSEQ : 0u);
 	prof_close(c, h, sx);
-	if (bt->n_frames) {
-		h = prof_open(c, "lz4_frame_sums", sx);
-		if (verify)
-			la_launch_lz4_frame_sums(sx, bt->d_src, bt->d_dst, bt->d_frames, bt->n_frames,
-			    bt->d_dst_off, bt->dst_cap, bt->d_frame_status);
-		else
-			HIPCHK(c, hipMemsetAsync(bt->d_frame_status, 0, (size_t)bt->n_frames * sizeof(uint32_t), sx));
-		prof_close(c, h, sx);
+	const uint32_t nsl = (fast && n >= 4u * 8192u) ? 4u : 1u;
+	if (bt->n_frames && !verify)
+		HIPCHK(c, hipMemsetAsync(bt->d_frame_status, 0, (size_t)bt->n_frames * sizeof(uint32_t), sx));
+	for (uint32_t i = 0; i < nsl; i++) {
+		const uint32_t first = (uint32_t)((uint64_t)n * i / nsl), last = (uint32_t)((uint64_t)n * (i + 1) / nsl);
+		if (fast) {
+			h = prof_open(c, "lz4_expand", sx);
+			la_launch_lz4_expand_fast(sx, bt->d_src, bt->src_bytes, bt->d_blocks + first, last - first, bt->d_dst,
+			    bt->dst_cap, bt->d_dst_off + first, bt->d_out_len + first, bt->d_block_status + first,
+			    w.nseq + first, w.table, w.table_off + first);
+			prof_close(c, h, sx);
+		}
+		if (bt->n_frames && verify) {
+			HIPCHK(c, hipEventRecord(c->slice_ev[1 + i], sx));
+			HIPCHK(c, hipStreamWaitEvent(sp, c->slice_ev[1 + i], 0));
+			h = prof_open(c, "lz4_frame_sums", sp);
+			/* frames that END in this slice: all their blocks are in the slab now */
+			la_launch_lz4_frame_sums(sp, bt->d_src, bt->d_dst, bt->d_frames, bt->n_frames,
+			    bt->d_dst_off, bt->dst_cap, bt->d_frame_status, i ? first + 1 : 0u, last);
+			prof_close(c, h, sp);
+		}
 	}
+	/* join the second stream */
+	HIPCHK(c, hipEventRecord(c->slice_ev[LA_MAX_SLICES - 1], sp));
+	HIPCHK(c, hipStreamWaitEvent(sx, c->slice_ev[LA_MAX_SLICES - 1], 0));
+	if (verify)
+		la_launch_lz4_merge_status(sx, w.sum_status, n, bt->d_block_status);
 	if (bt->d_summary) {
 		h = prof_open(c, "summary", sx);
 		la_launch_lz4_summary(sx, bt->d_out_len, bt->d_block_status, n,

@@ -102,6 +102,18 @@ __device__ __forceinline__ uint32_t xxh32_quad(const uint8_t *p, uint32_t len, u
 	if (len >= 16) {
 		uint32_t v = (j == 0) ? seed + XXH_P1 + XXH_P2 : (j == 1) ? seed + XXH_P2 : (j == 2) ? seed : seed - XXH_P1;
 		const uint8_t *q = p + 4 * j;
+		/* 512 bytes (32 stripes) of loads in flight per quad: the chain itself is short,
+		 * the stream must not wait for memory */
+		while (p + 512 <= end) {
+			uint32_t x[32];
+#pragma unroll
+			for (int t = 0; t < 32; t++)
+				x[t] = ld_u32(q + 16 * t);
+#pragma unroll
+			for (int t = 0; t < 32; t++)
+				v = xxh_round(v, x[t]);
+			p += 512; q += 512;
+		}
 		while (p + 128 <= end) {
 			uint32_t x0 = ld_u32(q), x1 = ld_u32(q + 16), x2 = ld_u32(q + 32), x3 = ld_u32(q + 48);
 			uint32_t x4 = ld_u32(q + 64), x5 = ld_u32(q + 80), x6 = ld_u32(q + 96), x7 = ld_u32(q + 112);
@@ -216,7 +228,8 @@ void la_launch_lz4_block_sums(hipStream_t s, const uint8_t *d_src, const la_lz4_
     uint32_t n, uint32_t *d_status);
 void la_launch_lz4_frame_sums(hipStream_t s, const uint8_t *d_src, const uint8_t *d_dst,
     const la_lz4_frame *d_frames, uint32_t n_frames, const uint64_t *d_dst_off,
-    uint64_t dst_cap, uint32_t *d_frame_status);
+    uint64_t dst_cap, uint32_t *d_frame_status, uint32_t end_lo, uint32_t end_hi);
+void la_launch_lz4_merge_status(hipStream_t s, const uint32_t *d_sum_status, uint32_t n, uint32_t *d_status);
 
 /* la_lz4.hip, la_lz4_fast.hip */
 struct la_lz4_seq {	/* one LZ4 sequence, 8 bytes, written by the parse kernel */

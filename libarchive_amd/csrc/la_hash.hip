@@ -28,6 +28,22 @@ __global__ __launch_bounds__(256) void xxh32_many_kernel(const uint8_t *__restri
 	out[i] = xxh32_lane(base + j.off, j.len, j.seed);
 }
 
+/* checksum verdicts outrank decode verdicts (the reference checks the block checksum
+ * first, lz4.c:517 vs :594): fold them into the per-block status */
+__global__ __launch_bounds__(256) void lz4_merge_status_kernel(const uint32_t *__restrict__ sum_status,
+    uint32_t n, uint32_t *__restrict__ status)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n && sum_status[i] != LA_ST_OK)
+		status[i] = sum_status[i];
+}
+
+void la_launch_lz4_merge_status(hipStream_t s, const uint32_t *d_sum_status, uint32_t n, uint32_t *d_status)
+{
+	if (n == 0) return;
+	hipLaunchKernelGGL(lz4_merge_status_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_sum_status, n, d_status);
+}
+
 /* block checksums: XXH32 over the compressed payload (lz4.c:517-526) */
 __global__ __launch_bounds__(256) void lz4_block_sums_kernel(const uint8_t *__restrict__ src,
     const la_lz4_block *__restrict__ blocks, uint32_t n, uint32_t *__restrict__ status)
@@ -48,7 +64,8 @@ __global__ __launch_bounds__(256) void lz4_block_sums_kernel(const uint8_t *__re
  * are few and their chains long. */
 __global__ __launch_bounds__(64) void lz4_frame_sums_kernel(const uint8_t *__restrict__ src,
     const uint8_t *__restrict__ dst, const la_lz4_frame *__restrict__ frames, uint32_t n,
-    const uint64_t *__restrict__ dst_off, uint64_t dst_cap, uint32_t *__restrict__ fstatus)
+    const uint64_t *__restrict__ dst_off, uint64_t dst_cap, uint32_t *__restrict__ fstatus,
+    uint32_t end_lo, uint32_t end_hi)
 {
 	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
 	uint32_t i = t >> 2;
@@ -56,6 +73,11 @@ __global__ __launch_bounds__(64) void lz4_frame_sums_kernel(const uint8_t *__res
 	if (i >= n)
 		return;		/* n is rounded so that whole quads leave together */
 	la_lz4_frame f = frames[i];
+	/* this launch takes the frames whose LAST block index + 1 lies in [end_lo, end_hi]
+	 * (the batch is expanded in slices; a frame is hashed once all its blocks exist) */
+	const uint32_t fend = f.first_block + f.n_blocks;
+	if (fend < end_lo || fend > end_hi)
+		return;
 	uint32_t st = LA_ST_OK;
 	if (f.flags & LA_LZ4F_HEADER_SUM) {
 		uint32_t h = xxh32_quad(src + f.desc_off, f.desc_len - 1, 0, j);
@@ -91,11 +113,11 @@ void la_launch_lz4_block_sums(hipStream_t s, const uint8_t *d_src, const la_lz4_
 
 void la_launch_lz4_frame_sums(hipStream_t s, const uint8_t *d_src, const uint8_t *d_dst,
     const la_lz4_frame *d_frames, uint32_t n_frames, const uint64_t *d_dst_off, uint64_t dst_cap,
-    uint32_t *d_frame_status)
+    uint32_t *d_frame_status, uint32_t end_lo, uint32_t end_hi)
 {
 	if (n_frames == 0) return;
 	hipLaunchKernelGGL(lz4_frame_sums_kernel, dim3((n_frames + 15) / 16), dim3(64), 0, s,
-	    d_src, d_dst, d_frames, n_frames, d_dst_off, dst_cap, d_frame_status);
+	    d_src, d_dst, d_frames, n_frames, d_dst_off, dst_cap, d_frame_status, end_lo, end_hi);
 }
 
 /* ------------------------------------------------------------------ CRC32 */
