@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--cpu-sample-mib", type=int, default=1024, help="decoded MiB the CPU baseline decodes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--general-only", action="store_true", help="force the general expand kernel")
+    ap.add_argument("--workload", choices=["lz4", "gzip"], default="lz4",
+                    help="lz4 = BASELINE configs[1] (the headline); gzip = configs[2] shape (64 KiB BGZF-style members)")
     return ap.parse_args()
 
 
@@ -103,8 +105,101 @@ def cpu_baseline(S, O, img_unique, idx_unique, sample_mib, budget_s=12.0):
                        % (reps, len(out) >> 20, want, dt)), out
 
 
+def _gz_make_member(args):
+    import struct, zlib
+    data, = args
+    co = zlib.compressobj(6, zlib.DEFLATED, -15, 9)
+    body = co.compress(data) + co.flush()
+    total = 18 + len(body) + 8
+    hdr = b"\x1f\x8b\x08\x04" + b"\0\0\0\0" + b"\x00\x03" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, total - 1)
+    return hdr + body + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data))
+
+
+def main_gzip(args):
+    """configs[2] shape: concatenated gzip members of 64 KiB with a BGZF-style size subfield,
+    CRC32 + ISIZE verified on the device.  Secondary line (the headline is the lz4 workload)."""
+    import multiprocessing as mp
+    import torch
+    import libarchive_amd as la
+    from libarchive_amd import _native as N
+    from libarchive_amd.gzip import GzDevicePlan
+    import streams as S
+
+    assert torch.cuda.is_available()
+    device = torch.device("cuda", 0)
+    ctx = la.GpuContext(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    uniq_mib = min(args.unique_mib, 256)
+    frames = (uniq_mib << 20) // (BPF * BLOCK)
+    _, plain = S.synth_lz4_stream(SEED, 0, frames, BPF, BLOCK, nthreads=min(16, os.cpu_count() or 1))
+    pieces = [(plain[i:i + BLOCK].tobytes(),) for i in range(0, plain.size, BLOCK)]
+    with mp.get_context("fork").Pool(min(16, os.cpu_count() or 1)) as pool:
+        members = pool.map(_gz_make_member, pieces, chunksize=64)
+    img = np.frombuffer(b"".join(members), dtype=np.uint8)
+    idx = la.gz_index(img, at_eof=True)
+    assert len(idx.members) == len(pieces) and idx.speculative == 0
+    tiles = max(1, int(round(args.gib * (1 << 30) / plain.size)))
+    nm, clen = len(idx.members), int(img.size)
+    d_src = torch.from_numpy(img.copy()).to(device).repeat(tiles)
+    mem = np.tile(idx.members, tiles)
+    t_of = np.repeat(np.arange(tiles, dtype=np.uint64), nm)
+    mem["src_off"] += t_of * np.uint64(clen)
+    mem["dst_off"] += t_of * np.uint64(idx.max_out)
+    tiled = N.GzIndex(mem, None, idx.end_kind, clen * tiles, idx.max_out * tiles, 0)
+    plan = GzDevicePlan(ctx, d_src, tiled)
+    C_bytes, U_bytes = int(d_src.numel()), int(tiled.max_out)
+    for _ in range(args.warmup):
+        plan.run()
+    torch.cuda.synchronize()
+    ctx.profile_enable(True)
+    phase_ms = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        plan.run()
+        for name, ms in ctx.profile_read():
+            phase_ms.setdefault(name, []).append(ms)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    sm = plan.summary()
+    ok = int(sm["n_bad_units"]) == 0 and int(sm["total_out"]) == U_bytes
+    ok = ok and bool(torch.equal(plan.d_dst[:plain.size].cpu(), torch.from_numpy(plain)))
+    for t in range(1, tiles):
+        ok = ok and bool(torch.equal(plan.d_dst[:plain.size], plan.d_dst[t * plain.size:(t + 1) * plain.size]))
+    cpu = None
+    if not args.no_cpu_baseline:
+        import oracle_lib as O
+        reps, el, t1 = 0, 0.0, time.time()
+        while el < 10.0:
+            out, res = O.gzip_stream_decode(img, plain.size + 64)
+            reps += 1
+            el = time.time() - t1
+        assert res.rc == 0 and np.array_equal(out, plain)
+        cpu = dict(value=round(reps * plain.size / el / (1 << 20), 1), unit="MiB/s", cores=1, kind="port",
+                   sample="%d x %d MiB decoded, oracle gzip filter (inflate + trailer CRC32), %.1f s" % (reps, plain.size >> 20, el))
+    inf_ms = float(np.mean(phase_ms.get("inflate", [float("nan")])))
+    ach = (C_bytes + U_bytes) / (inf_ms * 1e-3) / 1e9
+    print(json.dumps({
+        "metric": "decompressed MiB/s (whole node), gzip filter, CRC32 verified, bit-exact",
+        "value": round(U_bytes * args.steps / dt / (1 << 20), 1), "unit": "MiB/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "C3 shape: raw-format + gzip filter, %.2f GiB decoded, %d BGZF-style 64 KiB members (zlib level 6), CRC32+ISIZE verified"
+                               % (U_bytes / (1 << 30), plan.n),
+                   "compressed_bytes_per_gpu": C_bytes, "decoded_bytes_per_gpu": U_bytes},
+        "bit_exact": bool(ok), "phases_ms": {k: round(float(np.mean(v)), 3) for k, v in phase_ms.items()},
+        "roofline": {"bound": "hbm", "kernel": "inflate", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                     "algorithmic_bytes": C_bytes + U_bytes},
+        "cpu_baseline": cpu}), flush=True)
+    ctx.close()
+    if not ok:
+        sys.exit(3)
+
+
 def main():
     args = parse()
+    if args.workload == "gzip":
+        return main_gzip(args)
     import torch
     import torch.distributed as dist
     import libarchive_amd as la
@@ -173,6 +268,12 @@ def main():
             sample_ok = bool(np.array_equal(got, ref_out))
             ok_all = ok_all and sample_ok
         exp_ms = float(np.mean(phase_ms.get("lz4_expand", [float("nan")])))
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tpath) and abs(args.gib - 16.0) < 1e-6 and not args.general_only:
+            # PMC-measured HBM bytes of the expand kernel for this exact workload (separate
+            # rocprofv3 --pmc passes, committed under profiles/), summed over its slice launches
+            traffic = json.load(open(tpath))["lz4_expand_fast_kernel"]["hbm_bytes_per_step"]
         achieved = (C_bytes + U_bytes) / (exp_ms * 1e-3) / 1e9
         step_ms = dt_max / args.steps * 1e3
         line = {
@@ -209,8 +310,9 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None,
+                "traffic": traffic,
                 "algorithmic_bytes": C_bytes + U_bytes,
+                "launches_per_step": 4 if (plan.n_blocks >= 32768 and not args.general_only) else 1,
                 "whole_step_frac": round((C_bytes + U_bytes) / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             },
             "cpu_baseline": cpu,

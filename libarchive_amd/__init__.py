@@ -20,6 +20,10 @@ from ._native import (  # noqa: F401
     gpu_lib,
     host_lib,
     lz4_index,
+    gz_index,
+    GzIndex,
+    GZ_MEMBER_DTYPE,
+    GZ_RESULT_DTYPE,
     status_message,
     end_message,
 )

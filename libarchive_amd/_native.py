@@ -169,6 +169,44 @@ def lz4_index(image, at_eof: bool = True) -> Lz4Index:
         host_lib().la_lz4_index_free(C.byref(c))
 
 
+GZ_HEADER_DTYPE = np.dtype([("off", "<u8"), ("len", "<u4"), ("mtime", "<u4"), ("name_off", "<u4"), ("bgzf_size", "<u4")])
+
+
+class _GzIndexC(C.Structure):
+    _fields_ = [("members", C.c_void_p), ("headers", C.c_void_p), ("n", C.c_uint32), ("cap", C.c_uint32),
+                ("end_kind", C.c_int), ("consumed", C.c_uint64), ("max_out", C.c_uint64), ("speculative", C.c_int)]
+
+
+class GzIndex:
+    """Member table of a .gz image (host walker, la_gz_index_build)."""
+
+    def __init__(self, members, headers, end_kind, consumed, max_out, speculative):
+        self.members, self.headers = members, headers
+        self.end_kind, self.consumed, self.max_out, self.speculative = end_kind, consumed, max_out, speculative
+
+
+def gz_index(image, at_eof: bool = True) -> GzIndex:
+    if isinstance(image, (bytes, bytearray, memoryview)):
+        image = np.frombuffer(bytes(image), dtype=np.uint8)
+    image = np.ascontiguousarray(image, dtype=np.uint8)
+    lib = host_lib()
+    lib.la_gz_index_build.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(_GzIndexC)]
+    lib.la_gz_index_free.argtypes = [C.POINTER(_GzIndexC)]
+    lib.la_gz_index_free.restype = None
+    c = _GzIndexC()
+    if lib.la_gz_index_build(image.ctypes.data, image.size, 1 if at_eof else 0, C.byref(c)) != 0:
+        raise MemoryError("la_gz_index_build")
+    try:
+        mem = np.empty(c.n, dtype=GZ_MEMBER_DTYPE)
+        hdr = np.empty(c.n, dtype=GZ_HEADER_DTYPE)
+        if c.n:
+            C.memmove(mem.ctypes.data, c.members, mem.nbytes)
+            C.memmove(hdr.ctypes.data, c.headers, hdr.nbytes)
+        return GzIndex(mem, hdr, c.end_kind, c.consumed, c.max_out, c.speculative)
+    finally:
+        lib.la_gz_index_free(C.byref(c))
+
+
 class GpuContext:
     """la_gpu_ctx: one HIP stream + workspace on one device."""
 

@@ -1,0 +1,19 @@
+#!/bin/bash
+# HBM traffic counters of the lz4 kernels at full size (separate --pmc passes, MI355X_MICROARCH.md HBM section)
+out=$1
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out.fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out.write.log 2>&1
+python - <<PY
+import csv,glob,collections,json
+res=collections.defaultdict(dict)
+for p in ("fetch","write"):
+    for f in glob.glob("$out/%s/*/*counter_collection.csv"%p):
+        acc=collections.defaultdict(float); cnt=collections.Counter()
+        for r in csv.DictReader(open(f)):
+            k=r["Kernel_Name"].split("(")[0].replace("void ","")[:40]
+            acc[k]+=float(r["Counter_Value"]); cnt[k]+=1
+        for k in acc:
+            if "lz4" in k or "scan" in k: res[k][p+"_kb_per_launch"]=acc[k]/cnt[k]; res[k]["launches"]=cnt[k]
+print(json.dumps(res, indent=1))
+PY
