@@ -212,7 +212,9 @@ typedef struct la_gz_batch {
 	uint32_t            reserved;
 } la_gz_batch;
 
-#define LA_GZ_OPT_NO_VERIFY 1u	/* do not compare the trailer (reference behaviour) */
+#define LA_GZ_OPT_NO_VERIFY   1u	/* do not compare the trailer (reference behaviour) */
+#define LA_GZ_OPT_WAVE_KERNEL 2u	/* force the wave-per-member kernel (default: lane-per-member from 512 members up) */
+#define LA_GZ_OPT_LANE_KERNEL 4u	/* force the lane-per-member kernel */
 
 int la_gpu_gzip_decode(la_gpu_ctx *ctx, const la_gz_batch *batch);
 

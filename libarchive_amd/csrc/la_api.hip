@@ -13,6 +13,7 @@
 #include <new>
 
 #define LA_MAX_SLICES 8
+#define LA_GZ_LANES_MIN 512u	/* members per batch from which the lane-per-member kernel is used */
 #define LA_PROF_MAX_RANGES 64
 
 struct la_gpu_ctx {
@@ -412,10 +413,24 @@ int la_gpu_gzip_decode(la_gpu_ctx *c, const la_gz_batch *bt)
 	if (bt->n_members && (!bt->d_src || !bt->d_members || !bt->d_dst || !bt->d_results))
 		return LA_ERR_ARG;
 	hipStream_t s = c->stream;
+	/* many members: one LANE per member (la_inflate_lanes.hip); few: one wave per member */
+	const bool lanes = (bt->n_members >= LA_GZ_LANES_MIN || (bt->options & LA_GZ_OPT_LANE_KERNEL)) &&
+	    !(bt->options & LA_GZ_OPT_WAVE_KERNEL);
+	if (lanes) {
+		uint64_t need = la_inflate_lanes_scratch_bytes(bt->n_members);
+		if (need > c->ws_bytes) {
+			int rc = la_gpu_reserve(c, need);
+			if (rc != LA_OK) return rc;
+		}
+	}
 	prof_begin(c);
 	int h = prof_open(c, "inflate", s);
-	la_launch_inflate(s, bt->d_src, bt->src_bytes, bt->d_members, bt->n_members, bt->d_dst, bt->dst_cap,
-	    bt->d_results);
+	if (lanes)
+		la_launch_inflate_lanes(s, bt->d_src, bt->src_bytes, bt->d_members, bt->n_members, bt->d_dst,
+		    bt->dst_cap, bt->d_results, c->ws);
+	else
+		la_launch_inflate(s, bt->d_src, bt->src_bytes, bt->d_members, bt->n_members, bt->d_dst, bt->dst_cap,
+		    bt->d_results);
 	prof_close(c, h, s);
 	h = prof_open(c, "gz_crc32", s);
 	la_launch_gz_verify(s, bt->d_src, bt->src_bytes, bt->d_members, bt->n_members, bt->d_dst,

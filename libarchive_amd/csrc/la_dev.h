@@ -265,6 +265,10 @@ void la_launch_lz4_expand_fast(hipStream_t s, const uint8_t *d_src, uint64_t src
 /* la_inflate.hip */
 void la_launch_inflate(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
     const la_gz_member *d_members, uint32_t n, uint8_t *d_dst, uint64_t dst_cap, la_gz_result *d_results);
+uint64_t la_inflate_lanes_scratch_bytes(uint32_t n);
+void la_launch_inflate_lanes(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
+    const la_gz_member *d_members, uint32_t n, uint8_t *d_dst, uint64_t dst_cap, la_gz_result *d_results,
+    void *d_scratch);
 void la_launch_gz_verify(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
     const la_gz_member *d_members, uint32_t n, const uint8_t *d_dst, la_gz_result *d_results, int verify);
 void la_launch_gz_summary(hipStream_t s, const la_gz_result *d_results, uint32_t n, la_batch_summary *d_summary);

@@ -1,0 +1,445 @@
+/*
+ * la_inflate_lanes.hip -- raw DEFLATE decode, ONE LANE PER MEMBER (gfx950).
+ *
+ * Same job and same accept/reject rules as la_inflate.hip (zlib inflate(),
+ * gzip.c:431-511 / :479; rules in oracle/orc_inflate.c), different shape: a
+ * deflate stream is one serial bit chain, so for batches of MANY independent
+ * members (BGZF-style multi-member streams, SURVEY config 3: 262 144 members)
+ * the parallel axis is "members", exactly as the LZ4 parse kernel walks one token
+ * chain per lane.  Each lane owns
+ *   - a 64-bit bit buffer refilled with unaligned 8-byte loads of its member,
+ *   - its Huffman fast tables in LDS, TRANSPOSED ([entry][lane]) so that 64
+ *     lanes looking up 64 different codes never meet in a bank:
+ *         256 x u16 literal/length table (8-bit index) + 64 x u16 distance table
+ *         (6-bit index) = 640 B per lane, 256 lanes = the CU's whole 160 KiB;
+ *     longer codes fall back to a canonical walk over per-lane arrays in a
+ *     global scratch area (rare),
+ *   - its output slot in the slab: literals are single byte stores, matches are
+ *     8-byte "wild" copies (a lane reads back its own earlier stores, which the
+ *     hardware keeps coherent per thread; bytes past a match are overwritten by
+ *     what follows, and never lie beyond the member's slot).
+ * The wave-per-member kernel of la_inflate.hip stays the path for small batches
+ * and for members whose slot is too small for wild copies.
+ */
+#include "la_dev.h"
+
+#ifndef IL_THREADS
+#define IL_THREADS 256
+#endif
+#ifndef LL_BITS
+#define LL_BITS 8
+#endif
+#define DT_BITS 6
+#define IL_SCRATCH_PER_LANE 1024u	/* bytes of global scratch per member: lens[320] + sorted symbols u16[320] + pad */
+
+/* ---- per-lane LDS tables, transposed: element e of lane t at [e][t] ---- */
+struct il_lds {
+	uint16_t ll[1 << LL_BITS][IL_THREADS];
+	uint16_t dt[1 << DT_BITS][IL_THREADS];
+};
+
+/* 16 counters of up to 15 bits each, packed 4 per u64 (dynamic index without scratch) */
+struct packed16 {
+	uint64_t w[4];
+};
+__device__ __forceinline__ uint32_t p16_get(const packed16 &p, uint32_t i)
+{
+	const uint64_t v = (i >> 2) == 0 ? p.w[0] : (i >> 2) == 1 ? p.w[1] : (i >> 2) == 2 ? p.w[2] : p.w[3];
+	return (uint32_t)(v >> (16 * (i & 3))) & 0xFFFFu;
+}
+__device__ __forceinline__ void p16_add(packed16 &p, uint32_t i, uint32_t add)
+{
+	const uint64_t a = (uint64_t)add << (16 * (i & 3));
+	if ((i >> 2) == 0) p.w[0] += a; else if ((i >> 2) == 1) p.w[1] += a;
+	else if ((i >> 2) == 2) p.w[2] += a; else p.w[3] += a;
+}
+__device__ __forceinline__ void p16_zero(packed16 &p) { p.w[0] = p.w[1] = p.w[2] = p.w[3] = 0; }
+
+struct lane_bits {
+	const uint8_t *s;	/* member's first deflate byte */
+	uint64_t hold;
+	uint64_t cur, nxt;	/* the 8 bytes at ip and at ip+8: nxt is requested one refill ahead */
+	uint32_t bits;		/* valid bits in hold */
+	uint32_t ip;		/* next byte to feed into hold */
+	uint32_t iend;		/* bytes of the member's span */
+	uint32_t room;		/* bytes from s to the end of the source image */
+};
+
+__device__ __forceinline__ uint64_t lb_load8(const lane_bits &B, uint32_t at)
+{
+	uint64_t v;
+	if ((uint64_t)at + 8 <= B.room)
+		__builtin_memcpy(&v, B.s + at, 8);
+	else {
+		v = 0;	/* tail of the image: never read past it */
+		for (uint32_t k = 0; k < 8; k++)
+			if (at + k < B.room)
+				v |= (uint64_t)B.s[at + k] << (8 * k);
+	}
+	return v;
+}
+
+__device__ __forceinline__ void lb_start(lane_bits &B)
+{
+	B.hold = 0; B.bits = 0; B.ip = 0;
+	B.cur = lb_load8(B, 0);
+	B.nxt = lb_load8(B, 8);
+}
+
+/* re-aim the byte window after the stored-block path moved ip by hand */
+__device__ __forceinline__ void lb_seek(lane_bits &B, uint32_t ip)
+{
+	B.ip = ip; B.bits = 0; B.hold = 0;
+	B.cur = lb_load8(B, ip);
+	B.nxt = lb_load8(B, ip + 8);
+}
+
+/* top the buffer up to >= 56 bits.  The bytes come from `cur`; the load that replaces
+ * what was used is issued now and only needed at the NEXT refill, so its latency is
+ * hidden behind the symbols in between.  Bytes past iend may come along (they exist in
+ * the image or are zero) and are never COUNTED as available: see lb_avail(). */
+__device__ __forceinline__ void lb_refill(lane_bits &B)
+{
+	B.hold |= B.cur << B.bits;
+	const uint32_t take = (63u - B.bits) >> 3;
+	B.bits += take * 8;
+	if (take) {
+		B.ip += take;
+		B.cur = (B.cur >> (8 * take)) | (B.nxt << (64 - 8 * take));
+		B.nxt = lb_load8(B, B.ip + 8);
+	}
+}
+/* bits of REAL input still unread (may be negative when the buffer ran past iend) */
+__device__ __forceinline__ int32_t lb_avail(const lane_bits &B)
+{
+	return (int32_t)B.bits - (int32_t)((int64_t)B.ip - (int64_t)B.iend) * 8 * (B.ip > B.iend ? 1 : 0);
+}
+__device__ __forceinline__ uint32_t lb_peek(const lane_bits &B, uint32_t n) { return (uint32_t)B.hold & ((1u << n) - 1u); }
+__device__ __forceinline__ void lb_drop(lane_bits &B, uint32_t n) { B.hold >>= n; B.bits -= n; }
+
+/* per-lane canonical code description kept in registers for the slow path */
+struct lane_code {
+	packed16 count;		/* codes per length 1..15 */
+	uint32_t maxlen;
+};
+
+/*
+ * Build one table from lens[0..n) (global scratch, this lane's): counts, sorted symbol
+ * list (global scratch, for codes longer than the fast table) and the LDS fast table.
+ * Returns 0 complete, >0 incomplete, <0 over-subscribed.
+ */
+template <int FAST_BITS>
+__device__ int il_build(const uint8_t *lens, int n, lane_code &C, uint16_t *sorted,
+    uint16_t (*fast)[IL_THREADS], int tid)
+{
+	p16_zero(C.count);
+	for (int i = 0; i < n; i++)
+		p16_add(C.count, lens[i], 1);
+	int left = 1, maxlen = 0;
+	packed16 next_off, next_code;
+	p16_zero(next_off); p16_zero(next_code);
+	uint32_t off = 0, code = 0;
+	for (int l = 1; l < 16; l++) {
+		const uint32_t c = p16_get(C.count, l);
+		if (c) maxlen = l;
+		left = left * 2 - (int)c;
+		if (left < 0) left = -100000;
+		p16_add(next_off, l, off);
+		off += c;
+		code = (code + (l > 1 ? p16_get(C.count, l - 1) : 0)) << 1;
+		p16_add(next_code, l, code & 0x7FFFu);
+	}
+	C.maxlen = (uint32_t)maxlen;
+	for (int i = 0; i < (1 << FAST_BITS); i++)
+		fast[i][tid] = 0;
+	if (left < 0)
+		return -1;
+	for (int sy = 0; sy < n; sy++) {
+		const uint32_t l = lens[sy];
+		if (l == 0) continue;
+		const uint32_t pos = p16_get(next_off, l);
+		p16_add(next_off, l, 1);
+		sorted[pos] = (uint16_t)sy;
+		const uint32_t cw = p16_get(next_code, l);
+		p16_add(next_code, l, 1);
+		if (l <= (uint32_t)FAST_BITS) {
+			const uint32_t r = __builtin_bitreverse32(cw) >> (32 - l);
+			const uint16_t e = (uint16_t)((sy << 4) | l);
+			for (uint32_t idx = r; idx < (1u << FAST_BITS); idx += (1u << l))
+				fast[idx][tid] = e;
+		}
+	}
+	return left;
+}
+
+/* decode one symbol; *used = bits consumed.  >= 0 symbol, -2 unassigned code.
+ * The caller checks availability of the consumed bits afterwards. */
+template <int FAST_BITS>
+__device__ __forceinline__ int il_decode(lane_bits &B, const lane_code &C, const uint16_t *sorted,
+    uint16_t (*fast)[IL_THREADS], int tid, uint32_t *used)
+{
+	const uint32_t e = fast[lb_peek(B, FAST_BITS)][tid];
+	const uint32_t l = e & 15;
+	if (l) {
+		lb_drop(B, l);
+		*used = l;
+		return (int)(e >> 4);
+	}
+	/* long or unassigned code: canonical walk, one bit at a time */
+	int codev = 0, first = 0, index = 0;
+	const uint32_t ml = C.maxlen ? C.maxlen : 1;
+	for (uint32_t k = 1; k <= ml; k++) {
+		codev |= (int)(B.hold & 1);
+		lb_drop(B, 1);
+		const int cn = (int)p16_get(C.count, k);
+		if (codev - cn < first) {
+			*used = k;
+			return sorted[index + (codev - first)];
+		}
+		index += cn;
+		first += cn;
+		first <<= 1;
+		codev <<= 1;
+	}
+	*used = ml;
+	return -2;
+}
+
+__device__ __constant__ uint16_t il_len_base[29] = { 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31,
+	35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258 };
+__device__ __constant__ uint8_t il_len_extra[29] = { 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2,
+	3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0 };
+__device__ __constant__ uint16_t il_dist_base[30] = { 1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193,
+	257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577 };
+__device__ __constant__ uint8_t il_dist_extra[30] = { 0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6,
+	7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13 };
+__device__ __constant__ uint8_t il_clc_order[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
+
+/* the symbol just taken needed bits the member does not have */
+#define IL_CHECK_TRUNC()  do { if (lb_avail(B) < 0) { status = LA_ST_GZ_TRUNCATED; goto done; } } while (0)
+
+__global__ __launch_bounds__(IL_THREADS) void inflate_lanes_kernel(const uint8_t *__restrict__ src,
+    uint64_t src_bytes, const la_gz_member *__restrict__ members, uint32_t n, uint8_t *dst,
+    uint64_t dst_cap, la_gz_result *__restrict__ results, uint8_t *scratch)
+{
+	__shared__ il_lds T;
+	const int tid = threadIdx.x;
+	const uint32_t mi = blockIdx.x * IL_THREADS + tid;
+	if (mi >= n)
+		return;
+	const la_gz_member m = members[mi];
+	uint8_t *lens = scratch + (uint64_t)mi * IL_SCRATCH_PER_LANE;		/* [320] */
+	uint16_t *sorted_ll = (uint16_t *)(lens + 320);				/* [288] */
+	uint16_t *sorted_d = sorted_ll + 288;					/* [32] */
+	uint32_t status = LA_ST_OK;
+	lane_bits B;
+	B.s = src + m.src_off;
+	B.iend = m.src_len;
+	{
+		uint64_t room = m.src_off < src_bytes ? src_bytes - m.src_off : 0;
+		B.room = room > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)room;
+		if (B.iend > B.room) B.iend = B.room;
+	}
+	lb_start(B);
+	uint8_t *d = dst + m.dst_off;
+	uint32_t cap = m.dst_cap;
+	if (m.dst_off + m.dst_cap > dst_cap)
+		cap = m.dst_off < dst_cap ? (uint32_t)(dst_cap - m.dst_off) : 0;
+	uint32_t op = 0;
+	lane_code CL, CD;
+	CL.maxlen = CD.maxlen = 0;
+	p16_zero(CL.count); p16_zero(CD.count);
+
+	for (;;) {
+		lb_refill(B);
+		const uint32_t last = lb_peek(B, 1);
+		const uint32_t type = (lb_peek(B, 3) >> 1);
+		lb_drop(B, 3);
+		IL_CHECK_TRUNC();
+		if (type == 0) {
+			/* stored: to the byte boundary, LEN / NLEN, raw bytes */
+			lb_drop(B, B.bits & 7);
+			lb_refill(B);
+			const uint32_t v = (uint32_t)B.hold;
+			lb_drop(B, 32);
+			IL_CHECK_TRUNC();
+			const uint32_t len = v & 0xFFFFu, nlen = v >> 16;
+			if (len != (nlen ^ 0xFFFFu)) { status = LA_ST_GZ_DATA; goto done; }
+			/* whole bytes still in the bit buffer go back to the byte stream */
+			B.ip -= B.bits >> 3;
+			const uint32_t avail = B.ip < B.iend ? B.iend - B.ip : 0;
+			const uint32_t take = len < avail ? len : avail;
+			if (op + take > cap) { status = LA_ST_GZ_OUT_FULL; goto done; }
+			for (uint32_t j = 0; j < take; j++)
+				d[op + j] = B.s[B.ip + j];
+			op += take;
+			lb_seek(B, B.ip + take);
+			if (take < len) { status = LA_ST_GZ_TRUNCATED; goto done; }
+		} else if (type == 1 || type == 2) {
+			int nlen = 288, ndist = 32;
+			if (type == 1) {
+				for (int i = 0; i < 320; i++)
+					lens[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : i < 288 ? 8 : 5;
+			} else {
+				lb_refill(B);
+				nlen = (int)lb_peek(B, 5) + 257; lb_drop(B, 5);
+				ndist = (int)lb_peek(B, 5) + 1; lb_drop(B, 5);
+				const int ncode = (int)lb_peek(B, 4) + 4; lb_drop(B, 4);
+				IL_CHECK_TRUNC();
+				if (nlen > 286 || ndist > 30) { status = LA_ST_GZ_DATA; goto done; }
+				for (int i = 0; i < 19; i++)
+					lens[i] = 0;
+				for (int i = 0; i < ncode; i++) {
+					if (B.bits < 3) lb_refill(B);
+					lens[il_clc_order[i]] = (uint8_t)lb_peek(B, 3);
+					lb_drop(B, 3);
+					IL_CHECK_TRUNC();
+				}
+				/* code-length code: 19 symbols, <= 7 bits; its fast table borrows the distance table */
+				lane_code CC;
+				const int e = il_build<DT_BITS>(lens, 19, CC, sorted_d, T.dt, tid);
+				if (e != 0 && CC.maxlen != 0) { status = LA_ST_GZ_DATA; goto done; }
+				int idx = 0;
+				uint32_t prev = 0;
+				if (CC.maxlen == 0) {
+					/* zlib 1.2.11: an all-zero code-length code yields one-bit "length 0" symbols */
+					lb_refill(B);
+					if (lb_avail(B) < 1) { status = LA_ST_GZ_TRUNCATED; goto done; }
+					for (; idx < nlen + ndist; idx++) {
+						if (B.bits < 1) lb_refill(B);
+						lb_drop(B, 1);
+						IL_CHECK_TRUNC();
+						lens[idx] = 0;
+					}
+				} else {
+					while (idx < nlen + ndist) {
+						lb_refill(B);
+						uint32_t used;
+						const int sym = il_decode<DT_BITS>(B, CC, sorted_d, T.dt, tid, &used);
+						IL_CHECK_TRUNC();
+						if (sym < 0) { status = LA_ST_GZ_DATA; goto done; }
+						if (sym < 16) {
+							lens[idx++] = (uint8_t)sym;
+							prev = (uint32_t)sym;
+							continue;
+						}
+						int rep;
+						uint32_t val = 0;
+						if (sym == 16) {
+							rep = 3 + (int)lb_peek(B, 2); lb_drop(B, 2);
+							IL_CHECK_TRUNC();
+							if (idx == 0) { status = LA_ST_GZ_DATA; goto done; }
+							val = prev;
+						} else if (sym == 17) {
+							rep = 3 + (int)lb_peek(B, 3); lb_drop(B, 3);
+							IL_CHECK_TRUNC();
+						} else {
+							rep = 11 + (int)lb_peek(B, 7); lb_drop(B, 7);
+							IL_CHECK_TRUNC();
+						}
+						if (idx + rep > nlen + ndist) { status = LA_ST_GZ_DATA; goto done; }
+						for (int t = 0; t < rep; t++)
+							lens[idx + t] = (uint8_t)val;
+						prev = val;
+						idx += rep;
+					}
+				}
+				if (lens[256] == 0) { status = LA_ST_GZ_DATA; goto done; }
+			}
+			{
+				int e = il_build<LL_BITS>(lens, nlen, CL, sorted_ll, T.ll, tid);
+				if (e < 0 || (e > 0 && CL.maxlen != 1)) { status = LA_ST_GZ_DATA; goto done; }
+				e = il_build<DT_BITS>(lens + nlen, ndist, CD, sorted_d, T.dt, tid);
+				if (e < 0 || (e > 0 && CD.maxlen > 1)) { status = LA_ST_GZ_DATA; goto done; }
+			}
+			/* ---- symbols ---- */
+			for (;;) {
+				/* 48 bits cover one literal/length code, its extra bits, a distance code and
+				 * its extra bits (15 + 5 + 15 + 13): reload only when fewer are left, i.e.
+				 * every few symbols instead of every symbol */
+				if (B.bits < 48)
+					lb_refill(B);
+				uint32_t used;
+				int sym = il_decode<LL_BITS>(B, CL, sorted_ll, T.ll, tid, &used);
+				IL_CHECK_TRUNC();
+				if (sym < 0) { status = LA_ST_GZ_DATA; goto done; }
+				if (sym < 256) {
+					if (op >= cap) { status = LA_ST_GZ_OUT_FULL; goto done; }
+					d[op++] = (uint8_t)sym;
+					continue;
+				}
+				if (sym == 256)
+					break;
+				sym -= 257;
+				if (sym >= 29) { status = LA_ST_GZ_DATA; goto done; }
+				uint32_t xb = il_len_extra[sym];
+				const uint32_t length = il_len_base[sym] + lb_peek(B, xb);
+				lb_drop(B, xb);
+				IL_CHECK_TRUNC();
+				const int ds = il_decode<DT_BITS>(B, CD, sorted_d, T.dt, tid, &used);
+				IL_CHECK_TRUNC();
+				if (ds < 0 || ds >= 30) { status = LA_ST_GZ_DATA; goto done; }
+				xb = il_dist_extra[ds];
+				const uint32_t dist = il_dist_base[ds] + lb_peek(B, xb);
+				lb_drop(B, xb);
+				IL_CHECK_TRUNC();
+				if (dist > op) { status = LA_ST_GZ_DATA; goto done; }
+				if (op + length > cap) { status = LA_ST_GZ_OUT_FULL; goto done; }
+				uint8_t *o = d + op;
+				const uint8_t *f = o - dist;
+				if (dist >= 16 && op + length + 16 <= cap) {
+					/* wild 16-byte copies (two loads in flight, then two stores): bytes past
+					 * the match are rewritten by what follows */
+					for (uint32_t i = 0; i < length; i += 16) {
+						uint64_t v0, v1;
+						__builtin_memcpy(&v0, f + i, 8);
+						__builtin_memcpy(&v1, f + i + 8, 8);
+						__builtin_memcpy(o + i, &v0, 8);
+						__builtin_memcpy(o + i + 8, &v1, 8);
+					}
+				} else if (dist >= 8 && op + length + 8 <= cap) {
+					for (uint32_t i = 0; i < length; i += 8) {
+						uint64_t v;
+						__builtin_memcpy(&v, f + i, 8);
+						__builtin_memcpy(o + i, &v, 8);
+					}
+				} else {
+					for (uint32_t i = 0; i < length; i++)
+						o[i] = f[i];
+				}
+				op += length;
+			}
+		} else {
+			status = LA_ST_GZ_DATA;
+			goto done;
+		}
+		if (last)
+			break;
+	}
+done:
+	{
+		/* bytes consumed = up to and including the byte that holds the last bit used */
+		uint32_t consumed = B.ip - (B.bits >> 3);
+		if (consumed > B.iend) consumed = B.iend;
+		la_gz_result r;
+		r.status = status;
+		r.out_len = op;
+		r.consumed = consumed;
+		r.crc32 = 0;
+		results[mi] = r;
+	}
+}
+
+uint64_t la_inflate_lanes_scratch_bytes(uint32_t n)
+{
+	return (uint64_t)n * IL_SCRATCH_PER_LANE + 256;
+}
+
+void la_launch_inflate_lanes(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
+    const la_gz_member *d_members, uint32_t n, uint8_t *d_dst, uint64_t dst_cap, la_gz_result *d_results,
+    void *d_scratch)
+{
+	if (n == 0) return;
+	hipLaunchKernelGGL(inflate_lanes_kernel, dim3((n + IL_THREADS - 1) / IL_THREADS), dim3(IL_THREADS), 0, s,
+	    d_src, src_bytes, d_members, n, d_dst, dst_cap, d_results, (uint8_t *)d_scratch);
+}

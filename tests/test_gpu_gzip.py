@@ -14,6 +14,17 @@ ST_OK, ST_DATA, ST_TRUNC, ST_BAD_CRC, ST_BAD_ISIZE, ST_FULL, ST_NOTRAILER = 0, 5
 
 
 def gpu_inflate(ctx, bodies, caps, verify=True):
+    """Runs BOTH deflate kernels (wave per member, lane per member) and insists they agree."""
+    a, sa = _gpu_inflate(ctx, bodies, caps, verify, 2)
+    b, sb = _gpu_inflate(ctx, bodies, caps, verify, 4)
+    # `consumed` only means something when the deflate stream ended (status OK / trailer verdicts)
+    norm = lambda rs: [(st, out, cons if st in (ST_OK, ST_BAD_CRC, ST_BAD_ISIZE, ST_NOTRAILER) else None, crc) for st, out, cons, crc in rs]
+    assert norm(a) == norm(b), "wave-per-member and lane-per-member kernels disagree"
+    assert int(sa["n_bad_units"]) == int(sb["n_bad_units"]) and int(sa["total_out"]) == int(sb["total_out"])
+    return a, sa
+
+
+def _gpu_inflate(ctx, bodies, caps, verify, kernel_opt):
     """bodies: list of bytes (deflate body [+ trailer]); returns list of (status, out bytes, consumed, crc)."""
     import torch
     from libarchive_amd import _native as N
@@ -34,7 +45,7 @@ def gpu_inflate(ctx, bodies, caps, verify=True):
     bt.d_members = d_mem.data_ptr(); bt.n_members = len(bodies)
     bt.d_dst = d_dst.data_ptr(); bt.dst_cap = do
     bt.d_results = d_res.data_ptr(); bt.d_summary = d_sum.data_ptr()
-    bt.options = 0 if verify else 1
+    bt.options = (0 if verify else 1) | kernel_opt
     ctx.gzip_decode(bt)
     ctx.sync()
     res = d_res.cpu().numpy().view(N.GZ_RESULT_DTYPE)
