@@ -37,7 +37,15 @@
 #ifndef POLL_SLEEP
 #define POLL_SLEEP 1
 #endif
+#ifndef FAST_THREADS
 #define FAST_THREADS 512
+#endif
+#ifndef LBATCH
+#define LBATCH 2	/* payload chunks a thread has in flight in phase L */
+#endif
+#ifndef FAST_MIN_WAVES
+#define FAST_MIN_WAVES 4
+#endif
 #define FAST_WAVES   (FAST_THREADS / 64)
 
 /* Diagnostic build only (make diag, -DLA_DIAG): per-workgroup phase stamps go to a
@@ -100,7 +108,7 @@ typedef uint64_t seq_t;
 #define STEPS_PER_SLOT (64u >> STEP_SHIFT)	/* steps held by one register slot of a wave */
 __device__ __forceinline__ uint32_t fast_seq_index(uint32_t r, uint32_t wave, uint32_t lane)
 {
-	return (((r * STEPS_PER_SLOT + (lane >> STEP_SHIFT)) * 8 + wave) << STEP_SHIFT) + (lane & (STEP_SEQS - 1));
+	return (((r * STEPS_PER_SLOT + (lane >> STEP_SHIFT)) * FAST_WAVES + wave) << STEP_SHIFT) + (lane & (STEP_SEQS - 1));
 }
 __device__ __forceinline__ seq_t seq_load(const la_lz4_seq *t, uint32_t k)
 {
@@ -112,7 +120,7 @@ __device__ __forceinline__ seq_t seq_load(const la_lz4_seq *t, uint32_t k)
 #define SEQ_OFF(e)     ((uint32_t)((e) >> 48))
 
 template <uint32_t MAXSEQ>
-__global__ __launch_bounds__(FAST_THREADS, 4) void lz4_expand_fast_kernel(
+__global__ __launch_bounds__(FAST_THREADS, FAST_MIN_WAVES) void lz4_expand_fast_kernel(
     const uint8_t *__restrict__ src, uint64_t src_bytes, const la_lz4_block *__restrict__ blocks,
     uint32_t n, uint8_t *__restrict__ dst, uint64_t dst_cap, const uint64_t *__restrict__ dst_off,
     const uint32_t *__restrict__ out_len, uint32_t *status_out,
@@ -120,7 +128,7 @@ __global__ __launch_bounds__(FAST_THREADS, 4) void lz4_expand_fast_kernel(
     const uint64_t *__restrict__ table_off)
 {
 	const uint32_t *status = status_out;
-	__shared__ __attribute__((aligned(16))) uint8_t win[65536 + 32];
+	__shared__ __attribute__((aligned(16))) uint8_t win[65536 + 96];	/* 16 alignment shift + slack for over-reads */
 	__shared__ uint16_t dstpos[MAXSEQ + 4];
 	__shared__ uint32_t donebits[MAXSEQ / 32];	/* one bit per sequence: its match is in the window */
 	__shared__ uint16_t chunk_first[2048 + 8];	/* per 32-byte payload chunk: first sequence with literals in or after it */
@@ -152,9 +160,9 @@ __global__ __launch_bounds__(FAST_THREADS, 4) void lz4_expand_fast_kernel(
 	constexpr uint32_t MAXSTEPS = MAXSEQ / FAST_THREADS;
 	/* the first two payload chunks of this thread (phase L) are requested right away:
 	 * they depend on nothing, and their latency overlaps the table prepass */
-	uint64_t vv[2][4];
+	uint64_t vv[LBATCH][4];
 #pragma unroll
-	for (int u = 0; u < 2; u++) {
+	for (int u = 0; u < LBATCH; u++) {
 		const uint32_t c0 = (u * FAST_THREADS + tid) << 5;
 		vv[u][0] = vv[u][1] = vv[u][2] = vv[u][3] = 0;
 		if (c0 < b.src_len) {
@@ -204,11 +212,11 @@ __global__ __launch_bounds__(FAST_THREADS, 4) void lz4_expand_fast_kernel(
 	 * literal bytes go to the window with unaligned 8-byte LDS stores.  Work is balanced
 	 * by payload bytes, and every payload byte is read once. */
 	const uint32_t nlit_chunks = chunk_first[2048];
-	for (uint32_t base = 0; base < nlit_chunks; base += 2 * FAST_THREADS) {
-		uint32_t kk[2];
-		seq_t pe[2][6];
+	for (uint32_t base = 0; base < nlit_chunks; base += LBATCH * FAST_THREADS) {
+		uint32_t kk[LBATCH];
+		seq_t pe[LBATCH][6];
 #pragma unroll
-		for (int u = 0; u < 2; u++) {
+		for (int u = 0; u < LBATCH; u++) {
 			const uint32_t c = base + u * FAST_THREADS + tid;
 			kk[u] = c < nlit_chunks ? (uint32_t)chunk_first[c] : 0xFFFFFFFFu;
 			if (base != 0) {	/* payloads beyond 32 KiB: later chunks are loaded here */
@@ -230,13 +238,13 @@ __global__ __launch_bounds__(FAST_THREADS, 4) void lz4_expand_fast_kernel(
 			}
 		}
 #pragma unroll
-		for (int u = 0; u < 2; u++) {
+		for (int u = 0; u < LBATCH; u++) {
 #pragma unroll
 			for (int t = 0; t < 6; t++)
 				pe[u][t] = (kk[u] != 0xFFFFFFFFu && kk[u] + t < ns) ? seq_load(tab, kk[u] + t) : 0;
 		}
 #pragma unroll
-		for (int u = 0; u < 2; u++) {
+		for (int u = 0; u < LBATCH; u++) {
 			if (kk[u] == 0xFFFFFFFFu)
 				continue;
 			const uint32_t c0 = (base + u * FAST_THREADS + tid) << 5, c1 = c0 + 32;
@@ -338,6 +346,10 @@ __global__ __launch_bounds__(FAST_THREADS, 4) void lz4_expand_fast_kernel(
 			atomicOr(&donebits[k >> 5], 1u << (k & 31));
 
 		for (;;) {
+#ifdef LA_DIAG
+			if (lane == 0 && la_diag_stamps) atomicAdd(&la_diag_stamps[(size_t)blockIdx.x * 8 + 6], 1ull);
+			const unsigned long long t_it0 = __builtin_readcyclecounter();
+#endif
 			if (!fin) {
 				/* advance q over finished sequences, a 32-bit word of flags at a time */
 				while (q < qstop) {
@@ -362,27 +374,35 @@ __global__ __launch_bounds__(FAST_THREADS, 4) void lz4_expand_fast_kernel(
 					uint8_t *mp = W + mdst;
 					const uint8_t *fp = W + s0;
 					if (off >= mlen) {
-						/* source and destination do not overlap: 8 bytes per LDS op,
-						 * the first 32 bytes fetched before anything is stored */
-						uint32_t i = 0;
-						if (mlen >= 32) {
-							for (; i + 32 <= mlen; i += 32) {
-								uint64_t a0 = lds_ld8(fp + i), a1 = lds_ld8(fp + i + 8);
-								uint64_t a2 = lds_ld8(fp + i + 16), a3 = lds_ld8(fp + i + 24);
-								lds_st8(mp + i, a0); lds_st8(mp + i + 8, a1);
-								lds_st8(mp + i + 16, a2); lds_st8(mp + i + 24, a3);
+						/* Source and destination do not overlap.  ONE LDS round trip per 64
+						 * bytes: every load is issued before anything is stored, and the
+						 * ragged end is one more 8-byte (or 4-byte) copy placed so that it
+						 * ENDS with the match -- overlapping stores instead of a cascade of
+						 * 4/2/1-byte ones.  Loads may run past the source into later window
+						 * bytes or the slack behind the window; stores never pass the match. */
+						if (mlen >= 8) {
+							for (uint32_t i = 0; i < mlen; i += 64) {
+								uint64_t a[8];
+#pragma unroll
+								for (int j = 0; j < 8; j++)
+									a[j] = lds_ld8(fp + i + 8 * j);
+								const uint32_t n = mlen - i < 64 ? mlen - i : 64;
+								const uint64_t tail = lds_ld8(fp + i + n - 8);	/* n >= 8 here or i == 0 */
+								const uint32_t full = n >> 3;
+#pragma unroll
+								for (int j = 0; j < 8; j++)
+									if ((uint32_t)j < full)
+										lds_st8(mp + i + 8 * j, a[j]);
+								if (n & 7)
+									lds_st8(mp + i + n - 8, tail);
 							}
+						} else {
+							uint32_t lo4, hi4;	/* 4 <= mlen <= 7: two overlapping 4-byte copies */
+							__builtin_memcpy(&lo4, fp, 4);
+							__builtin_memcpy(&hi4, fp + mlen - 4, 4);
+							lds_st4(mp, lo4);
+							lds_st4(mp + mlen - 4, hi4);
 						}
-						uint32_t rem = mlen - i;	/* < 32 */
-						uint64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-						if (rem >= 8) a0 = lds_ld8(fp + i); else a0 = lds_ld_tail(fp + i, rem);
-						if (rem >= 16) a1 = lds_ld8(fp + i + 8); else if (rem > 8) a1 = lds_ld_tail(fp + i + 8, rem - 8);
-						if (rem >= 24) a2 = lds_ld8(fp + i + 16); else if (rem > 16) a2 = lds_ld_tail(fp + i + 16, rem - 16);
-						if (rem > 24) a3 = lds_ld_tail(fp + i + 24, rem - 24);
-						if (rem >= 8) lds_st8(mp + i, a0); else lds_st_tail(mp + i, a0, rem);
-						if (rem >= 16) lds_st8(mp + i + 8, a1); else if (rem > 8) lds_st_tail(mp + i + 8, a1, rem - 8);
-						if (rem >= 24) lds_st8(mp + i + 16, a2); else if (rem > 16) lds_st_tail(mp + i + 16, a2, rem - 16);
-						if (rem > 24) lds_st_tail(mp + i + 24, a3, rem - 24);
 					} else if (off >= 8) {
 						/* overlapping, period >= 8: a forward 8-byte copy only reads bytes
 						 * that this thread stored at least one iteration earlier */
@@ -405,6 +425,9 @@ __global__ __launch_bounds__(FAST_THREADS, 4) void lz4_expand_fast_kernel(
 					fin = true;
 				}
 			}
+#ifdef LA_DIAG
+			if (lane == 0 && la_diag_stamps) atomicAdd(&la_diag_stamps[(size_t)blockIdx.x * 8 + 7], __builtin_readcyclecounter() - t_it0);
+#endif
 			if (__ballot(!fin) == 0)
 				break;
 			__builtin_amdgcn_s_sleep(POLL_SLEEP);	/* back off: polling waves share the LDS with copying ones */

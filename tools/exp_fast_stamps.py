@@ -30,6 +30,6 @@ for i, nme in enumerate(names):
     d = st[:, i + 1] - st[:, i]
     print("  %-18s mean %8.0f  median %8.0f  share %.1f%%" % (nme, d.mean(), np.median(d), 100 * d.sum() / tot.sum()))
 raw = stamps.cpu().numpy().reshape(nb, 8).astype(np.uint64)
-print("per block: steps with a slow-path dependency check %.1f, serial (hazard) steps %.1f, sub-groups that spun %.1f, spin iterations %.1f"
-      % ((raw[:, 6] >> np.uint64(32)).mean(), (raw[:, 6] & np.uint64(0xFFFFFFFF)).mean(),
-         (raw[:, 7] >> np.uint64(32)).mean(), (raw[:, 7] & np.uint64(0xFFFFFFFF)).mean()))
+its = raw[:, 6].astype(np.float64); cyc = raw[:, 7].astype(np.float64)
+print("match phase per block: poll-loop iterations summed over 8 waves x steps: %.0f (%.1f per wave-step of ~4), cycles inside iterations summed: %.0f => %.0f cycles per iteration"
+      % (its.mean(), its.mean() / 32, cyc.mean(), cyc.mean() / its.mean()))
