@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--cpu-sample-mib", type=int, default=1024, help="decoded MiB the CPU baseline decodes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--general-only", action="store_true", help="force the general expand kernel")
+    ap.add_argument("--extra-options", type=int, default=0, help="diagnostic: extra LA_LZ4_OPT_* bits")
     ap.add_argument("--workload", choices=["lz4", "gzip"], default="lz4",
                     help="lz4 = BASELINE configs[1] (the headline); gzip = configs[2] shape (64 KiB BGZF-style members)")
     return ap.parse_args()
@@ -224,7 +225,7 @@ def main():
     plan = Lz4DevicePlan(ctx, d_src, tiled)
     C_bytes = int(d_src.numel())
     U_bytes = int(tiled.max_out)  # every synthetic block decodes to exactly 64 KiB
-    opts = N.LA_LZ4_OPT_GENERAL_ONLY if args.general_only else 0
+    opts = (N.LA_LZ4_OPT_GENERAL_ONLY if args.general_only else 0) | args.extra_options
 
     def barrier():
         if world > 1:

@@ -154,6 +154,8 @@ typedef struct la_batch_summary {
 
 #define LA_LZ4_OPT_GENERAL_ONLY 1u	/* force the general (any block size / dependent) expand kernel */
 #define LA_LZ4_OPT_NO_VERIFY    2u	/* skip the three XXH32 checks (the reference's `!stream-checksum` shape) */
+#define LA_LZ4_OPT_PARSE_V1     4u	/* first-generation parse: block checksums and token walk as two kernels
+					 * reading global memory per lane (kept as a cross-check of the staged one) */
 
 typedef struct la_lz4_batch {
 	const uint8_t      *d_src;	/* compressed image (or batch window) in HBM */

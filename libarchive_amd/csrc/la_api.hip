@@ -342,18 +342,27 @@ int la_gpu_lz4_decode(la_gpu_ctx *c, const la_lz4_batch *bt)
 		la_launch_lz4_table_caps(sp, bt->d_blocks, n, w.caps);
 		la_launch_scan_u32(sp, w.caps, n, w.table_off, w.scan);
 	}
-	/* block checksums into their own verdict array, then the parse (measured: running the two
-	 * side by side on two streams is slower than back to back) */
-	if (verify && n) {
+	/* block checksums (into their own verdict array) and the token-chain parse: one fused
+	 * kernel that stages the image through LDS and reads it from HBM once; the
+	 * first-generation pair of kernels stays selectable as a cross-check */
+	if (verify && n)
 		HIPCHK(c, hipMemsetAsync(w.sum_status, 0, (size_t)n * sizeof(uint32_t), sp));
-		h = prof_open(c, "lz4_block_sums", sp);
-		la_launch_lz4_block_sums(sp, bt->d_src, bt->d_blocks, n, w.sum_status);
+	if (bt->options & LA_LZ4_OPT_PARSE_V1) {
+		if (verify && n) {
+			h = prof_open(c, "lz4_block_sums", sp);
+			la_launch_lz4_block_sums(sp, bt->d_src, bt->d_blocks, n, w.sum_status);
+			prof_close(c, h, sp);
+		}
+		h = prof_open(c, "lz4_parse", sp);
+		la_launch_lz4_parse(sp, bt->d_src, bt->src_bytes, bt->d_blocks, n, bt->d_out_len, w.nseq,
+		    bt->d_block_status, fast ? w.table : NULL, w.table_off, w.table_cap);
+		prof_close(c, h, sp);
+	} else {
+		h = prof_open(c, "lz4_parse", sp);
+		la_launch_lz4_parse_staged(sp, bt->d_src, bt->src_bytes, bt->d_blocks, n, bt->d_out_len, w.nseq,
+		    bt->d_block_status, verify ? w.sum_status : NULL, fast ? w.table : NULL, w.table_off, w.table_cap);
 		prof_close(c, h, sp);
 	}
-	h = prof_open(c, "lz4_parse", sp);
-	la_launch_lz4_parse(sp, bt->d_src, bt->src_bytes, bt->d_blocks, n, bt->d_out_len, w.nseq,
-	    bt->d_block_status, fast ? w.table : NULL, w.table_off, w.table_cap);
-	prof_close(c, h, sp);
 	HIPCHK(c, hipEventRecord(c->slice_ev[0], sp));
 
 	HIPCHK(c, hipStreamWaitEvent(sx, c->slice_ev[0], 0));

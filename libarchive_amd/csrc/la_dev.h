@@ -253,6 +253,12 @@ void la_launch_lz4_parse(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes
     const la_lz4_block *d_blocks, uint32_t n, uint32_t *d_out_len, uint32_t *d_nseq,
     uint32_t *d_status, la_lz4_seq *d_table /* NULL: measure only */, const uint64_t *d_table_off,
     uint64_t table_cap /* entries */);
+/* la_lz4_parse.hip: the same parse fed from an LDS-staged image, block checksums fused in
+ * (d_sum_status NULL: no checksums) */
+void la_launch_lz4_parse_staged(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
+    const la_lz4_block *d_blocks, uint32_t n, uint32_t *d_out_len, uint32_t *d_nseq,
+    uint32_t *d_status, uint32_t *d_sum_status, la_lz4_seq *d_table, const uint64_t *d_table_off,
+    uint64_t table_cap);
 void la_launch_lz4_expand_general(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
     const la_lz4_block *d_blocks, uint32_t n, uint8_t *d_dst, uint64_t dst_cap,
     const uint64_t *d_dst_off, const uint32_t *d_out_len, const uint32_t *d_status,

@@ -18,14 +18,16 @@ MANIFEST = [e for e in json.load(open(os.path.join(GOLD, "manifest.json"))) if e
 
 def gpu_decode(ctx, image, options=None):
     """Runs BOTH expand paths (LDS-window kernel + general kernel, and general kernel only)
-    and insists that they agree before returning the result."""
+    and BOTH parse generations (LDS-staged fused parse+checksum, and the two first-generation
+    kernels) and insists that all of them agree before returning the result."""
     from libarchive_amd.lz4 import decode_image
     from libarchive_amd import _native as N
     res = []
-    for opt in ((0, N.LA_LZ4_OPT_GENERAL_ONLY) if options is None else (options,)):
+    for opt in ((0, N.LA_LZ4_OPT_GENERAL_ONLY, N.LA_LZ4_OPT_PARSE_V1,
+                 N.LA_LZ4_OPT_PARSE_V1 | N.LA_LZ4_OPT_GENERAL_ONLY) if options is None else (options,)):
         out, rc, msg, plan = decode_image(ctx, image, options=opt)
         res.append((out.tobytes(), rc, msg))
-    assert all(r == res[0] for r in res), "fast and general expand kernels disagree"
+    assert all(r == res[0] for r in res), "kernel variants disagree (expand fast/general x parse staged/v1)"
     return res[0]
 
 

@@ -1,7 +1,10 @@
 #!/bin/bash
-# time the expand kernel of several builds on a 2 GiB workload (diagnostic)
+# time the kernels of several builds (libla_gpu_<name>.so) on a 4 GiB workload (diagnostic);
+# the shipped library is restored afterwards
+cp libarchive_amd/csrc/libla_gpu.so /tmp/libla_gpu_keep.so
 for v in "$@"; do
   cp libarchive_amd/csrc/libla_gpu_$v.so libarchive_amd/csrc/libla_gpu.so
   echo "== $v"
-  timeout -k 5 120 python bench.py --gib 2 --unique-mib 256 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['bit_exact'], d['phases_ms'])"
+  timeout -k 5 120 python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['bit_exact'], d['ms_per_step'], d['phases_ms'])"
 done
+cp /tmp/libla_gpu_keep.so libarchive_amd/csrc/libla_gpu.so
