@@ -128,7 +128,7 @@ __global__ __launch_bounds__(FAST_THREADS, FAST_MIN_WAVES) void lz4_expand_fast_
     const uint64_t *__restrict__ table_off)
 {
 	const uint32_t *status = status_out;
-	__shared__ __attribute__((aligned(16))) uint8_t win[65536 + 96];	/* 16 alignment shift + slack for over-reads */
+	__shared__ __attribute__((aligned(16))) uint8_t win[16 + 65536 + 96];	/* 16 headroom (literal stores may start 3 bytes early) + 16 alignment shift + slack for over-reads */
 	__shared__ uint16_t dstpos[MAXSEQ + 4];
 	__shared__ uint32_t donebits[MAXSEQ / 32];	/* one bit per sequence: its match is in the window */
 	__shared__ uint16_t chunk_first[2048 + 8];	/* per 32-byte payload chunk: first sequence with literals in or after it */
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(FAST_THREADS, FAST_MIN_WAVES) void lz4_expand_fast_
 	const uint8_t *s = src + b.src_off;
 	const uint64_t s_room = src_bytes - b.src_off;	/* bytes of the image from s on */
 	uint8_t *g_out = dst + doff;
-	uint8_t *W = win + ((uintptr_t)g_out & 15);	/* W[i] <-> g_out[i], congruent mod 16 */
+	uint8_t *W = win + 16 + ((uintptr_t)g_out & 15);	/* W[i] <-> g_out[i], congruent mod 16 */
 
 	/* This thread's sequences (fast_seq_index): their table entries are fetched once, up
 	 * front, and stay in registers for every pass over them.  The entry of the sequence
@@ -205,6 +205,9 @@ __global__ __launch_bounds__(FAST_THREADS, FAST_MIN_WAVES) void lz4_expand_fast_
 		}
 	}
 	__syncthreads();
+#ifdef LA_DIAG_L
+	STAMP(6);
+#endif
 
 	/* ---- phase L: literals, one thread per 32-byte payload chunk ----
 	 * Two coalesced 16-byte loads of the compressed stream per chunk; the chunk's
@@ -243,35 +246,45 @@ __global__ __launch_bounds__(FAST_THREADS, FAST_MIN_WAVES) void lz4_expand_fast_
 			for (int t = 0; t < 6; t++)
 				pe[u][t] = (kk[u] != 0xFFFFFFFFu && kk[u] + t < ns) ? seq_load(tab, kk[u] + t) : 0;
 		}
+#ifdef LA_DIAG_L
+		if (base == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(7); }
+#endif
 #pragma unroll
 		for (int u = 0; u < LBATCH; u++) {
 			if (kk[u] == 0xFFFFFFFFu)
 				continue;
 			const uint32_t c0 = (base + u * FAST_THREADS + tid) << 5, c1 = c0 + 32;
-			uint32_t k = kk[u];
-			for (uint32_t it = 0; k < ns; it++, k++) {
-				const seq_t e = it == 0 ? pe[u][0] : it == 1 ? pe[u][1] : it == 2 ? pe[u][2] :
-				    it == 3 ? pe[u][3] : it == 4 ? pe[u][4] : it == 5 ? pe[u][5] : seq_load(tab, k);
+			/* The chunk's eight dwords go out with STATIC register indices: dword m of
+			 * the chunk belongs to at most one literal run (two runs are at least a
+			 * 3-byte sequence header apart), and a whole-dword store may spill up to
+			 * three bytes over either end of the run: those bytes lie in the match
+			 * before / after the run (a match is at least four bytes long), which
+			 * phase M writes after the barrier.  No shifting, no register selects. */
+			const uint32_t dd[8] = { (uint32_t)vv[u][0], (uint32_t)(vv[u][0] >> 32), (uint32_t)vv[u][1], (uint32_t)(vv[u][1] >> 32),
+			    (uint32_t)vv[u][2], (uint32_t)(vv[u][2] >> 32), (uint32_t)vv[u][3], (uint32_t)(vv[u][3] >> 32) };
+			/* returns true when the chunk is finished */
+			auto put = [&](const seq_t e) -> bool {
 				const uint32_t ls = SEQ_LIT_SRC(e), le = ls + SEQ_LIT_LEN(e);
 				if (ls >= c1)
-					break;
+					return true;
 				const uint32_t lo = ls > c0 ? ls : c0, hi = le < c1 ? le : c1;
-				uint8_t *wp = W + SEQ_DST(e) + (lo - ls);
-				/* bytes [lo-c0, hi-c0) of the 32-byte register chunk -> window, 8 at a time */
-				for (uint32_t p0 = lo; p0 < hi; p0 += 8, wp += 8) {
-					const uint32_t i = p0 - c0, q = i >> 3, sh = (i & 7) * 8;
-					const uint64_t w0 = q == 0 ? vv[u][0] : q == 1 ? vv[u][1] : q == 2 ? vv[u][2] : vv[u][3];
-					const uint64_t w1 = q == 0 ? vv[u][1] : q == 1 ? vv[u][2] : q == 2 ? vv[u][3] : 0;
-					const uint64_t val = sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
-					const uint32_t nb = hi - p0;
-					if (nb >= 8)
-						lds_st8(wp, val);
-					else
-						lds_st_tail(wp, val, nb);
+				if (hi > lo) {
+					const uint32_t m0 = (lo - c0) >> 2, cnt = ((hi - c0 + 3) >> 2) - m0;
+					uint8_t *wb = W + SEQ_DST(e) + c0 - ls;	/* wb[p - c0] <-> payload[p]; W has 16 bytes of headroom */
+#pragma unroll
+					for (uint32_t m = 0; m < 8; m++)
+						if (m - m0 < cnt)
+							lds_st4(wb + 4 * m, dd[m]);
 				}
-				if (le >= c1)
-					break;
-			}
+				return le >= c1;
+			};
+			bool fin = false;
+#pragma unroll
+			for (int t = 0; t < 6; t++)
+				if (!fin)
+					fin = (kk[u] + t >= ns) || put(pe[u][t]);
+			for (uint32_t k = kk[u] + 6; !fin && k < ns; k++)	/* more than six sequences touch this chunk: rare */
+				fin = put(seq_load(tab, k));
 		}
 	}
 	STAMP(1);
@@ -346,7 +359,7 @@ __global__ __launch_bounds__(FAST_THREADS, FAST_MIN_WAVES) void lz4_expand_fast_
 			atomicOr(&donebits[k >> 5], 1u << (k & 31));
 
 		for (;;) {
-#ifdef LA_DIAG
+#if defined(LA_DIAG) && !defined(LA_DIAG_L)
 			if (lane == 0 && la_diag_stamps) atomicAdd(&la_diag_stamps[(size_t)blockIdx.x * 8 + 6], 1ull);
 			const unsigned long long t_it0 = __builtin_readcyclecounter();
 #endif
@@ -425,7 +438,7 @@ __global__ __launch_bounds__(FAST_THREADS, FAST_MIN_WAVES) void lz4_expand_fast_
 					fin = true;
 				}
 			}
-#ifdef LA_DIAG
+#if defined(LA_DIAG) && !defined(LA_DIAG_L)
 			if (lane == 0 && la_diag_stamps) atomicAdd(&la_diag_stamps[(size_t)blockIdx.x * 8 + 7], __builtin_readcyclecounter() - t_it0);
 #endif
 			if (__ballot(!fin) == 0)

@@ -33,3 +33,7 @@ raw = stamps.cpu().numpy().reshape(nb, 8).astype(np.uint64)
 its = raw[:, 6].astype(np.float64); cyc = raw[:, 7].astype(np.float64)
 print("match phase per block: poll-loop iterations summed over 8 waves x steps: %.0f (%.1f per wave-step of ~4), cycles inside iterations summed: %.0f => %.0f cycles per iteration"
       % (its.mean(), its.mean() / 32, cyc.mean(), cyc.mean() / its.mean()))
+if os.environ.get("LA_DIAG_L"):
+    # build with -DLA_DIAG_L: slot 6 = after the prepass barrier, slot 7 = table entries of the first literal batch arrived
+    a = st[:, 6] - st[:, 0]; b = st[:, 7] - st[:, 6]; c = st[:, 1] - st[:, 7]
+    print("phase L detail (thread 0): prepass+barrier %.0f, chunk_first + entry loads %.0f, literal stores %.0f" % (a.mean(), b.mean(), c.mean()))
