@@ -309,6 +309,12 @@ __global__ __launch_bounds__(FAST_THREADS, FAST_MIN_WAVES) void lz4_expand_fast_
 				qcur[r] = cand;
 		}
 	}
+	/* Literals are all in the window already (phase L), so a match only has to wait for
+	 * earlier MATCHES under its source range.  The last sequence the range touches is
+	 * often touched in its literal part only (a sequence is literals first, match second):
+	 * its entry tells, and then it drops out of the wait -- about a third of all waits,
+	 * and many sequences end up waiting for nothing at all. */
+	uint32_t qlast[MAXSTEPS], hib[MAXSTEPS];
 #pragma unroll
 	for (uint32_t r = 0; r < MAXSTEPS; r++) {
 		const uint32_t k = fast_seq_index(r, wave, lane);
@@ -319,6 +325,8 @@ __global__ __launch_bounds__(FAST_THREADS, FAST_MIN_WAVES) void lz4_expand_fast_
 			next = dstpos[k + 1];
 		const uint32_t mlen = k < ns ? next - mdst : 0;
 		uint32_t cnt = 0;	/* number of earlier sequences to wait for */
+		qlast[r] = 0xFFFFFFFFu;
+		hib[r] = 0;
 		if (mlen != 0 && s0 < d) {
 			const uint32_t span = mlen < off ? mlen : off;
 			uint32_t hi_byte = s0 + span - 1;
@@ -328,8 +336,20 @@ __global__ __launch_bounds__(FAST_THREADS, FAST_MIN_WAVES) void lz4_expand_fast_
 			while (qe + 1 < k && dstpos[qe + 1] <= hi_byte)
 				qe++;
 			cnt = qe - qcur[r] + 1;
+			qlast[r] = qe;
+			hib[r] = hi_byte;
 		}
 		qcur[r] = (qcur[r] & 0xFFFFu) | (cnt << 16);
+	}
+	{
+		seq_t le[MAXSTEPS];
+#pragma unroll
+		for (uint32_t r = 0; r < MAXSTEPS; r++)
+			le[r] = qlast[r] != 0xFFFFFFFFu ? seq_load(tab, qlast[r]) : 0;
+#pragma unroll
+		for (uint32_t r = 0; r < MAXSTEPS; r++)
+			if (qlast[r] != 0xFFFFFFFFu && hib[r] < SEQ_DST(le[r]) + SEQ_LIT_LEN(le[r]))
+				qcur[r] -= 1u << 16;	/* source ends inside the literals of the last sequence: its match is not needed */
 	}
 
 #pragma unroll 1
