@@ -14,5 +14,5 @@ for p in ("p1","p2"):
             k=r["Kernel_Name"].split("(")[0][:40]
             acc[k][r["Counter_Name"]]+=float(r["Counter_Value"])
         for k,d in acc.items():
-            if "lz4" in k: print(p,k,{a:int(b) for a,b in d.items()})
+            if "lz4" in k and "sums" not in k: print(p,k,{a:int(b) for a,b in d.items()})
 PY
