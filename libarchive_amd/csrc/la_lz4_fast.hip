@@ -413,28 +413,42 @@ __global__ __launch_bounds__(FAST_THREADS, FAST_MIN_WAVES) void lz4_expand_fast_
 						 * ENDS with the match -- overlapping stores instead of a cascade of
 						 * 4/2/1-byte ones.  Loads may run past the source into later window
 						 * bytes or the slack behind the window; stores never pass the match. */
-						if (mlen >= 8) {
-							for (uint32_t i = 0; i < mlen; i += 64) {
-								uint64_t a[8];
+						{
+							/* first 64 bytes: one batch of loads serves short and long matches alike */
+							uint64_t a[8];
 #pragma unroll
-								for (int j = 0; j < 8; j++)
-									a[j] = lds_ld8(fp + i + 8 * j);
-								const uint32_t n = mlen - i < 64 ? mlen - i : 64;
-								const uint64_t tail = lds_ld8(fp + i + n - 8);	/* n >= 8 here or i == 0 */
+							for (int j = 0; j < 8; j++)
+								a[j] = lds_ld8(fp + 8 * j);
+							const uint32_t n = mlen < 64 ? mlen : 64;
+							const uint64_t tail = lds_ld8(fp + (n >= 8 ? n - 8 : 0));
+							if (mlen < 8) {
+								/* 4 <= mlen <= 7: two overlapping 4-byte stores */
+								lds_st4(mp, (uint32_t)a[0]);
+								lds_st4(mp + mlen - 4, (uint32_t)(a[0] >> (8 * (mlen - 4))));
+							} else {
 								const uint32_t full = n >> 3;
 #pragma unroll
 								for (int j = 0; j < 8; j++)
 									if ((uint32_t)j < full)
-										lds_st8(mp + i + 8 * j, a[j]);
+										lds_st8(mp + 8 * j, a[j]);
 								if (n & 7)
-									lds_st8(mp + i + n - 8, tail);
+									lds_st8(mp + n - 8, tail);
 							}
-						} else {
-							uint32_t lo4, hi4;	/* 4 <= mlen <= 7: two overlapping 4-byte copies */
-							__builtin_memcpy(&lo4, fp, 4);
-							__builtin_memcpy(&hi4, fp + mlen - 4, 4);
-							lds_st4(mp, lo4);
-							lds_st4(mp + mlen - 4, hi4);
+						}
+						for (uint32_t i = 64; i < mlen; i += 64) {
+							uint64_t a[8];
+#pragma unroll
+							for (int j = 0; j < 8; j++)
+								a[j] = lds_ld8(fp + i + 8 * j);
+							const uint32_t n = mlen - i < 64 ? mlen - i : 64;
+							const uint64_t tail = lds_ld8(fp + i + n - 8);	/* i >= 64: never before the source */
+							const uint32_t full = n >> 3;
+#pragma unroll
+							for (int j = 0; j < 8; j++)
+								if ((uint32_t)j < full)
+									lds_st8(mp + i + 8 * j, a[j]);
+							if (n & 7)
+								lds_st8(mp + i + n - 8, tail);
 						}
 					} else if (off >= 8) {
 						/* overlapping, period >= 8: a forward 8-byte copy only reads bytes
