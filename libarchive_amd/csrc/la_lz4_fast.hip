@@ -384,16 +384,16 @@ __global__ __launch_bounds__(FAST_THREADS, FAST_MIN_WAVES) void lz4_expand_fast_
 			const unsigned long long t_it0 = __builtin_readcyclecounter();
 #endif
 			if (!fin) {
-				/* advance q over finished sequences, a 32-bit word of flags at a time */
-				while (q < qstop) {
+				/* advance q over finished sequences: ONE look at the flag word of q per
+				 * iteration (a second look in the same iteration would only be another LDS
+				 * round trip for the whole wave; a wait that spans two words takes two
+				 * iterations) */
+				if (q < qstop) {
 					/* bit 0 of `word` is the flag of q; the zeros shifted in from the
 					 * top end the run at the word boundary */
-					uint32_t word = __hip_atomic_load(&donebits[q >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> (q & 31);
-					uint32_t inv = ~word;
-					uint32_t run = inv ? (uint32_t)__builtin_ctz(inv) : 32u;
-					if (run == 0)
-						break;
-					q += run;
+					const uint32_t word = __hip_atomic_load(&donebits[q >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> (q & 31);
+					const uint32_t inv = ~word;
+					q += inv ? (uint32_t)__builtin_ctz(inv) : 32u;
 				}
 				/* every wait is bounded: a dependency that never completes (impossible
 				 * for a table the parse kernel produced) fails the block instead of
