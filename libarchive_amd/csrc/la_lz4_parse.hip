@@ -16,12 +16,14 @@
  * image from HBM and spent 9 ms on 7.5 GB.  Here the wave stages the image through
  * LDS in rounds:
  *
- *   round r   the wave owns bytes [r*CH, (r+2)*CH) of each of its 64 blocks in an LDS
- *             ring (dword-transposed: ring[dword][lane], so a lane's reads never
- *             conflict with another lane's).  Chunk r+2 is in flight in registers.
+ *   round r   the wave owns chunks r and r+1 (CH bytes each, cut on the IMAGE's CH-byte
+ *             grid starting at the grid point before the block) of each of its 64
+ *             blocks in an LDS ring (dword-transposed: ring[dword][lane], so a lane's
+ *             reads never conflict with another lane's).  Chunk r+2 is in flight in
+ *             registers.
  *   load      CH/16 wave instructions per round; in each, CH/16 neighbouring lanes
- *             read one block's chunk as consecutive 16-byte pieces (whole cache
- *             lines, each fetched once).
+ *             read one block's chunk as consecutive 16-byte pieces = one whole,
+ *             aligned cache line, fetched exactly once.
  *   parse     every lane walks its own token chain out of the ring for as long as
  *             its token is staged (it may run up to one chunk ahead of the round,
  *             which evens out lanes whose sequences are short or long).
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(PS_THREADS) void lz4_parse_staged_kernel(const uint
     uint32_t *__restrict__ sum_status, la_lz4_seq *__restrict__ table,
     const uint64_t *__restrict__ table_off, uint64_t table_cap)
 {
-	__shared__ uint32_t ring[PS_WAVES][PS_RINGW + 1u][64];	/* last row = copy of row 0: a dword pair never wraps */
+	__shared__ uint32_t ring[PS_WAVES][PS_RINGW + 4u][64];	/* last rows = copies of rows 0..3: up to five consecutive dwords never wrap */
 	/* table entries wait here (transposed: conflict free) and leave in groups of eight = one
 	 * aligned 64-byte burst per lane (see la_lz4.hip), at the START of a round: the stores
 	 * then have a whole round of LDS-only work to complete in before the wave next waits on
@@ -110,7 +112,12 @@ __global__ __launch_bounds__(PS_THREADS) void lz4_parse_staged_kernel(const uint
 	const bool do_parse = have && !pre_failed && !(b.flags & LA_LZ4B_STORED);	/* (a payload of 2^31 bytes or more fails below: iend <= 0) */
 	const bool do_sum = SUMS && have && (b.flags & LA_LZ4B_CHECKSUM);
 	const uint64_t room64 = b.src_off < src_bytes ? src_bytes - b.src_off : 0;
-	const uint32_t stage_len = (do_parse || do_sum) ? b.src_len : 0u;
+	/* Chunks are cut on the IMAGE's CH-byte grid, not the block's: every cache line of the
+	 * image is then fetched by exactly one load (block-relative chunks straddle two lines
+	 * each and fetched 1.5x the image).  sk = where the block starts inside its first
+	 * chunk; staged position = payload position + sk. */
+	const uint32_t sk = (do_parse || do_sum) ? (uint32_t)(b.src_off & (PS_CH - 1u)) : 0u;
+	const uint32_t stage_len = (do_parse || do_sum) ? b.src_len + sk : 0u;	/* staged bytes, from the chunk grid */
 
 	/* ---- loader set-up: which block and piece this lane fetches in instruction i ---- */
 	ps_loader L;
@@ -118,8 +125,9 @@ __global__ __launch_bounds__(PS_THREADS) void lz4_parse_staged_kernel(const uint
 #pragma unroll
 	for (uint32_t k = 0; k < PS_PIECES; k++) {
 		const int from = (int)(k * PS_BPI + lane / PS_PIECES);
-		const uint32_t off_lo = __shfl((uint32_t)b.src_off, from), off_hi = __shfl((uint32_t)(b.src_off >> 32), from);
-		const uint32_t rm_lo = __shfl((uint32_t)room64, from), rm_hi = __shfl((uint32_t)(room64 >> 32), from);
+		const uint64_t a_off = b.src_off - sk, a_room = room64 + sk;	/* both from the grid point before the block */
+		const uint32_t off_lo = __shfl((uint32_t)a_off, from), off_hi = __shfl((uint32_t)(a_off >> 32), from);
+		const uint32_t rm_lo = __shfl((uint32_t)a_room, from), rm_hi = __shfl((uint32_t)(a_room >> 32), from);
 		L.ptr[k] = ((uint64_t)off_hi << 32) | off_lo;
 		L.room[k] = ((uint64_t)rm_hi << 32) | rm_lo;
 		L.need[k] = __shfl(stage_len, from);
@@ -140,8 +148,12 @@ __global__ __launch_bounds__(PS_THREADS) void lz4_parse_staged_kernel(const uint
 			const uint32_t slot_ = k_ * PS_BPI + lane / PS_PIECES;                    \
 			const uint32_t j_ = (((c_) * (PS_CH / 4u)) + 4u * piece) & (PS_RINGW - 1u); \
 			R[j_ + 0][slot_] = fl[k_].x;                                              \
-			if (j_ == 0)                                                              \
-				R[PS_RINGW][slot_] = fl[k_].x;                                    \
+			if (j_ == 0) {                                                            \
+				R[PS_RINGW + 0][slot_] = fl[k_].x;                                \
+				R[PS_RINGW + 1][slot_] = fl[k_].y;                                \
+				R[PS_RINGW + 2][slot_] = fl[k_].z;                                \
+				R[PS_RINGW + 3][slot_] = fl[k_].w;                                \
+			}                                                                         \
 			R[j_ + 1][slot_] = fl[k_].y;                                              \
 			R[j_ + 2][slot_] = fl[k_].z;                                              \
 			R[j_ + 3][slot_] = fl[k_].w;                                              \
@@ -172,6 +184,8 @@ __global__ __launch_bounds__(PS_THREADS) void lz4_parse_staged_kernel(const uint
 	uint32_t done = (!do_parse || !ok) ? 1u : 0u;
 	/* checksum state */
 	uint32_t v1 = XXH_P1 + XXH_P2, v2 = XXH_P2, v3 = 0, v4 = 0u - XXH_P1;
+	uint32_t hp = 0;	/* payload offset of the next stripe */
+	bool hfin = false;
 
 #define EMIT_SEQ(lit_src_, lit_len_, dst_, off_)                                                   \
 	do {                                                                                       \
@@ -207,8 +221,9 @@ __global__ __launch_bounds__(PS_THREADS) void lz4_parse_staged_kernel(const uint
 		/* one payload byte at offset p >= base: ring, or (length-extension runs and
 		 * literal runs longer than the ring) the image itself */
 		auto get_byte = [&](int p) -> uint32_t {
-			if ((uint32_t)p < se32)
-				return (R[((uint32_t)p >> 2) & (PS_RINGW - 1u)][lane] >> (8 * ((uint32_t)p & 3u))) & 0xffu;
+			const uint32_t sp = (uint32_t)p + sk;
+			if (sp < se32)
+				return (R[(sp >> 2) & (PS_RINGW - 1u)][lane] >> (8 * (sp & 3u))) & 0xffu;
 			return p < glimit ? (uint32_t)gs[p] : 0u;
 		};
 
@@ -217,10 +232,7 @@ __global__ __launch_bounds__(PS_THREADS) void lz4_parse_staged_kernel(const uint
 		 * literal-only sequence, failures).  The trip loop below only comes here for
 		 * lanes its branch-free fast path has turned away. */
 		auto careful_step = [&]() {
-			const uint32_t j0 = (uint32_t)ip >> 2, sh = ((uint32_t)ip & 3u) * 8u;
-			const uint32_t d0 = R[j0 & (PS_RINGW - 1u)][lane], d1 = R[(j0 + 1) & (PS_RINGW - 1u)][lane];
-			const uint32_t w0 = __builtin_amdgcn_alignbit(d1, d0, sh);
-			const uint32_t token = w0 & 0xffu;
+			const uint32_t token = get_byte(ip);
 			int length = (int)(token >> 4);
 			int p = ip + 1;
 			bool fail = false;
@@ -289,13 +301,13 @@ __global__ __launch_bounds__(PS_THREADS) void lz4_parse_staged_kernel(const uint
 		 * the careful step instead. ---- */
 		for (;;) {
 			const bool live = done == 0;
-			if (__ballot(live && (uint32_t)ip < rend) == 0)
+			if (__ballot(live && (uint32_t)ip + sk < rend) == 0)
 				break;
 			const bool full = EMIT && emit && nseq - nfl >= PS_STAGE;
-			const bool act = live && (uint32_t)ip + 8u <= se32 && !full;
-			const uint32_t uip = (uint32_t)ip, uop = (uint32_t)op;
-			const uint32_t row = (((uip >> 2) & (PS_RINGW - 1u)) << 6) | lane;
-			const uint32_t w0 = __builtin_amdgcn_alignbit(Rw[row + 64], Rw[row], uip << 3);
+			const uint32_t uip = (uint32_t)ip, uop = (uint32_t)op, sip = uip + sk;	/* sip: staged position of the token */
+			const bool act = live && sip + 8u <= se32 && !full;
+			const uint32_t row = (((sip >> 2) & (PS_RINGW - 1u)) << 6) | lane;
+			const uint32_t w0 = __builtin_amdgcn_alignbit(Rw[row + 64], Rw[row], sip << 3);
 			const uint32_t nib_l = (w0 >> 4) & 15u, nib_m = w0 & 15u, x1 = (w0 >> 8) & 0xffu;
 			const bool ext1 = nib_l == 15u;
 			const uint32_t ll = nib_l + (ext1 ? x1 : 0u);
@@ -303,8 +315,9 @@ __global__ __launch_bounds__(PS_THREADS) void lz4_parse_staged_kernel(const uint
 			const bool s1 = ext1 && (x1 == 255u || (int)(uip + 1u) >= iend - 15);
 			const uint32_t opl = uop + ll, q = p + ll;
 			const bool lastseq = (int)opl > oend - LZ4_MFLIMIT || (int)q > iend - (2 + 1 + LZ4_LASTLIT);
-			const uint32_t row2 = (((q >> 2) & (PS_RINGW - 1u)) << 6) | lane;
-			const uint32_t o3 = __builtin_amdgcn_alignbit(Rw[row2 + 64], Rw[row2], q << 3);
+			const uint32_t sq = q + sk;
+			const uint32_t row2 = (((sq >> 2) & (PS_RINGW - 1u)) << 6) | lane;
+			const uint32_t o3 = __builtin_amdgcn_alignbit(Rw[row2 + 64], Rw[row2], sq << 3);
 			const uint32_t off = o3 & 0xffffu, x2 = (o3 >> 16) & 0xffu;
 			const bool ext2 = nib_m == 15u;
 			const uint32_t ml = nib_m + 4u + (ext2 ? x2 : 0u);
@@ -314,8 +327,8 @@ __global__ __launch_bounds__(PS_THREADS) void lz4_parse_staged_kernel(const uint
 			/* offset not staged yet: a lane that runs ahead of the round simply waits for
 			 * the next chunk; one still inside chunk r has a literal run longer than the
 			 * ring and lets the careful step fetch the three bytes from the image */
-			const bool far = q + 4u > se32;
-			const bool hold = far && uip >= rend;
+			const bool far = sq + 4u > se32;
+			const bool hold = far && sip >= rend;
 			const bool slow = act && !hold && (s1 || lastseq || far || s2 || bad);
 			const bool commit = act && !hold && !slow;
 			if (EMIT && commit && emit)
@@ -332,34 +345,42 @@ __global__ __launch_bounds__(PS_THREADS) void lz4_parse_staged_kernel(const uint
 			}
 		}
 
-		/* ---- block checksum: the XXH32 stripes of chunk r ---- */
-		if (SUMS && do_sum && base < b.src_len) {
-			const uint32_t left = b.src_len - base;
-			const uint32_t nfull = (left < PS_CH ? left : PS_CH) >> 4;
+		/* ---- block checksum: the XXH32 stripes that START in chunk r (a stripe is 16 payload
+		 * bytes; on the image's chunk grid it may reach into chunk r+1, which is staged) ---- */
+		if (SUMS && do_sum && !hfin) {
 #pragma unroll
 			for (uint32_t sidx = 0; sidx < PS_PIECES; sidx++) {
-				if (sidx < nfull) {
-					const uint32_t j = ((base >> 2) + 4u * sidx) & (PS_RINGW - 1u);
-					v1 = xxh_round(v1, R[j + 0][lane]);
-					v2 = xxh_round(v2, R[j + 1][lane]);
-					v3 = xxh_round(v3, R[j + 2][lane]);
-					v4 = xxh_round(v4, R[j + 3][lane]);
+				const uint32_t sp = hp + sk;
+				if (hp + 16u <= b.src_len && sp < rend) {
+					const uint32_t rowh = (((sp >> 2) & (PS_RINGW - 1u)) << 6) | lane;
+					const uint32_t d0 = Rw[rowh], d1 = Rw[rowh + 64], d2 = Rw[rowh + 128], d3 = Rw[rowh + 192], d4 = Rw[rowh + 256];
+					const uint32_t sh = sp << 3;
+					v1 = xxh_round(v1, __builtin_amdgcn_alignbit(d1, d0, sh));
+					v2 = xxh_round(v2, __builtin_amdgcn_alignbit(d2, d1, sh));
+					v3 = xxh_round(v3, __builtin_amdgcn_alignbit(d3, d2, sh));
+					v4 = xxh_round(v4, __builtin_amdgcn_alignbit(d4, d3, sh));
+					hp += 16u;
 				}
 			}
-			if (left <= PS_CH) {
-				/* last chunk: merge, tail, avalanche (xxhash.c:268-291) */
+			if (hp + 16u > b.src_len && b.src_len + sk <= se32) {
+				/* no whole stripe left and the rest is staged: merge, tail, avalanche
+				 * (xxhash.c:268-291) */
 				uint32_t h = b.src_len >= 16 ? rotl32(v1, 1) + rotl32(v2, 7) + rotl32(v3, 12) + rotl32(v4, 18) : XXH_P5;
 				h += b.src_len;
-				uint32_t p = base + (nfull << 4);
-				for (; p + 4 <= b.src_len; p += 4)
-					h = rotl32(h + R[(p >> 2) & (PS_RINGW - 1u)][lane] * XXH_P3, 17) * XXH_P4;
+				uint32_t p = hp;
+				for (; p + 4 <= b.src_len; p += 4) {
+					const uint32_t sp = p + sk, rowh = (((sp >> 2) & (PS_RINGW - 1u)) << 6) | lane;
+					h = rotl32(h + __builtin_amdgcn_alignbit(Rw[rowh + 64], Rw[rowh], sp << 3) * XXH_P3, 17) * XXH_P4;
+				}
 				for (; p < b.src_len; p++) {
-					const uint32_t by = (R[(p >> 2) & (PS_RINGW - 1u)][lane] >> (8 * (p & 3u))) & 0xffu;
+					const uint32_t sp = p + sk;
+					const uint32_t by = (R[(sp >> 2) & (PS_RINGW - 1u)][lane] >> (8 * (sp & 3u))) & 0xffu;
 					h = rotl32(h + by * XXH_P5, 11) * XXH_P1;
 				}
 				h = xxh_avalanche(h);
 				if (h != b.block_sum)
 					sum_status[i] = LA_ST_LZ4_BAD_BLOCK_SUM;	/* outranks a decode failure: checked first, lz4.c:517 vs :594 */
+				hfin = true;
 			}
 		}
 
@@ -367,7 +388,7 @@ __global__ __launch_bounds__(PS_THREADS) void lz4_parse_staged_kernel(const uint
 		PS_STORE_CHUNK(r + 2u);
 		ps_load_chunk(src, L, r + 3u, piece, fl);
 	}
-	if (SUMS && do_sum && b.src_len == 0) {
+	if (SUMS && do_sum && !hfin && b.src_len == 0) {	/* (an empty payload on a grid point stages nothing) */
 		if (xxh_avalanche(XXH_P5) != b.block_sum)
 			sum_status[i] = LA_ST_LZ4_BAD_BLOCK_SUM;
 	}
