@@ -6,31 +6,50 @@
  *
  * One 512-thread workgroup owns one block; its whole output lives in a 64 KiB
  * LDS window (two workgroups per CU: 2 x 77 KiB of the 160 KiB LDS).  The
- * parse kernel has already reduced the token chain to
- *   - a table of sequences {literal source, literal length, output position,
- *     match offset}, and
- *   - a literal index: for every 16-byte chunk of the payload, the first
- *     sequence that still has literals in or after it,
- * so inside the block every copy is known up front:
+ * parse kernel has already reduced the token chain to a table of sequences
+ * {literal source, literal length, output position, match offset}, so inside
+ * the block every copy is known up front:
  *
- *   phase L (literals)  one thread per 16-byte payload chunk: ONE coalesced
- *       16-byte load of the compressed stream, the chunk's sequences from the
- *       literal index, literal bytes scattered into the window.  Work is
- *       balanced by bytes, not by sequences; every payload byte is read once.
+ *   prepass             every thread loads its sequences' entries (kept in
+ *       registers for all phases), publishes their output positions in LDS and
+ *       builds the chunk index: for every 32-byte chunk of the payload, the
+ *       first sequence that still has literals in or after it.
+ *   phase L (literals)  one thread per 32-byte payload chunk: two coalesced
+ *       16-byte loads of the compressed stream, the chunk's sequences from the
+ *       chunk index, literal bytes into the window as whole dwords with static
+ *       register indices.  Work is balanced by bytes, not by sequences; every
+ *       payload byte is read once.
  *   phase M (matches)   one thread per sequence, sequences taken in increasing
  *       order.  A match may read bytes an earlier match produces, so every
  *       sequence publishes a "done" bit in LDS and a match waits only for the
- *       (typically one to three) earlier sequences that overlap its source
- *       range, found by a binary search over the output positions.
- *       Dependencies always point to lower sequence numbers and waves take
- *       sequences in increasing order, so the lowest unfinished sequence can
- *       always run: no deadlock, no barrier inside the phase.
+ *       (typically one or two) earlier MATCHES that overlap its source range,
+ *       found by a binary search over the output positions.  Dependencies
+ *       always point to lower sequence numbers and waves take sequences in
+ *       increasing order, so the lowest unfinished sequence can always run: no
+ *       deadlock, no barrier inside the phase; every spin is bounded anyway.
  *   phase F (flush)     the window goes to the decoded slab with 16-byte
  *       coalesced stores (the window is placed so that LDS and HBM addresses
  *       are congruent modulo 16).
  *
- * HBM traffic per block: payload once, sequence table + literal index once in,
- * decoded bytes once out.
+ * HBM traffic per block: payload once, sequence table once in (plus the entries
+ * phase L looks up), decoded bytes once out.
+ *
+ * What bounds it (PMC, C2 workload): the LDS pipe is 66 % busy, the SIMDs about
+ * half, and behind both sits the dependency chain of phase M (DAG depth 16 per
+ * block, about 31 poll iterations per wave).  What a poll iteration costs is LDS
+ * round trips in series, LDS instructions, and VALU instructions, in that order.
+ * Measured on the way here (16 GiB C2 stream, expand ms):
+ *   - all loads of a match copy before any store, ragged end as an overlapping
+ *     end-aligned store                                           39.1 -> 32.8
+ *   - literal chunks as whole dwords, static register indices     32.7 -> 27.8
+ *   - no wait for a sequence touched only in its literals          27.8 -> 26.9
+ *   - short (4..7 byte) matches in the same load batch            26.9 -> 24.8
+ *   - one look at the flag word per iteration                      24.8 -> 23.5
+ * and slower, so not kept: wave-cooperative match copies (four matches per pass
+ * through ds_bpermute, 35.1), flag look requested one iteration ahead (28.3),
+ * speculative source read behind the flag look (27.6), 8-ary search (26.9 from
+ * 23.5: more LDS instructions), per-sequence literal copies from global memory
+ * (43.6), 256- and 1024-thread workgroups (no gain), longer poll sleeps (+1..4 %).
  */
 #include "la_dev.h"
 
