@@ -423,24 +423,73 @@ int la_gpu_gzip_decode(la_gpu_ctx *c, const la_gz_batch *bt)
 		return LA_ERR_ARG;
 	hipStream_t s = c->stream;
 	/* many members: one LANE per member (la_inflate_lanes.hip); few: one wave per member */
-	const bool lanes = (bt->n_members >= LA_GZ_LANES_MIN || (bt->options & LA_GZ_OPT_LANE_KERNEL)) &&
+	const bool lanes = (bt->n_members >= LA_GZ_LANES_MIN || (bt->options & (LA_GZ_OPT_LANE_KERNEL | LA_GZ_OPT_TWO_PHASE))) &&
 	    !(bt->options & LA_GZ_OPT_WAVE_KERNEL);
+	/* lanes, two phases (default): entropy decode into literal buffers + sequence tables, then the
+	 * LDS-window expand kernel of the lz4 path; LA_GZ_OPT_LANE_KERNEL forces the in-place lane kernel */
+	const bool two_phase = lanes && !(bt->options & LA_GZ_OPT_LANE_KERNEL);
+	const uint32_t n = bt->n_members;
+	uint8_t *wsb = NULL;
+	la_inflate_emit E = {};
 	if (lanes) {
-		uint64_t need = la_inflate_lanes_scratch_bytes(bt->n_members);
-		if (need > c->ws_bytes) {
-			int rc = la_gpu_reserve(c, need);
+		uint64_t need = align_up(la_inflate_lanes_scratch_bytes(n), 256);
+		const uint64_t o_scratch = 0;
+		uint64_t o = need;
+		uint64_t o_lit = 0, o_tab = 0, o_blk = 0, o_olen = 0, o_nseq = 0, o_xst = 0, o_todo = 0, o_doff = 0, o_toff = 0;
+		if (two_phase) {
+			o_lit = o;  o += align_up((uint64_t)n * 65536u, 256);
+			o_tab = o;  o += align_up((uint64_t)n * LA_LZ4_FAST_MAXSEQ * sizeof(la_lz4_seq), 256);
+			o_blk = o;  o += align_up((uint64_t)n * sizeof(la_lz4_block), 256);
+			o_olen = o; o += align_up((uint64_t)n * 4, 256);
+			o_nseq = o; o += align_up((uint64_t)n * 4, 256);
+			o_xst = o;  o += align_up((uint64_t)n * 4, 256);
+			o_todo = o; o += align_up((uint64_t)n * 4, 256);
+			o_doff = o; o += align_up((uint64_t)(n + 1) * 8, 256);
+			o_toff = o; o += align_up((uint64_t)(n + 1) * 8, 256);
+		}
+		if (o > c->ws_bytes) {
+			int rc = la_gpu_reserve(c, o);
 			if (rc != LA_OK) return rc;
+		}
+		wsb = (uint8_t *)c->ws;
+		(void)o_scratch;
+		if (two_phase) {
+			E.lit = wsb + o_lit;
+			E.table = (la_lz4_seq *)(wsb + o_tab);
+			E.blocks = (la_lz4_block *)(wsb + o_blk);
+			E.out_len = (uint32_t *)(wsb + o_olen);
+			E.nseq = (uint32_t *)(wsb + o_nseq);
+			E.xstatus = (uint32_t *)(wsb + o_xst);
+			E.todo = (uint32_t *)(wsb + o_todo);
+			E.dst_off = (uint64_t *)(wsb + o_doff);
+			E.table_off = (uint64_t *)(wsb + o_toff);
 		}
 	}
 	prof_begin(c);
-	int h = prof_open(c, "inflate", s);
-	if (lanes)
-		la_launch_inflate_lanes(s, bt->d_src, bt->src_bytes, bt->d_members, bt->n_members, bt->d_dst,
-		    bt->dst_cap, bt->d_results, c->ws);
-	else
-		la_launch_inflate(s, bt->d_src, bt->src_bytes, bt->d_members, bt->n_members, bt->d_dst, bt->dst_cap,
-		    bt->d_results);
-	prof_close(c, h, s);
+	int h;
+	if (two_phase) {
+		h = prof_open(c, "inflate_symbols", s);
+		la_launch_inflate_symbols(s, bt->d_src, bt->src_bytes, bt->d_members, n, bt->dst_cap, bt->d_results, wsb, E);
+		prof_close(c, h, s);
+		h = prof_open(c, "inflate_expand", s);
+		la_launch_lz4_expand_fast(s, E.lit, (uint64_t)n * 65536u, E.blocks, n, bt->d_dst, bt->dst_cap,
+		    E.dst_off, E.out_len, E.xstatus, E.nseq, E.table, E.table_off);
+		prof_close(c, h, s);
+		/* members the LDS-window kernel cannot take: decoded in place */
+		h = prof_open(c, "inflate", s);
+		la_launch_inflate_lanes(s, bt->d_src, bt->src_bytes, bt->d_members, n, bt->d_dst,
+		    bt->dst_cap, bt->d_results, wsb, E.todo);
+		prof_close(c, h, s);
+	} else {
+		h = prof_open(c, "inflate", s);
+		if (lanes)
+			la_launch_inflate_lanes(s, bt->d_src, bt->src_bytes, bt->d_members, n, bt->d_dst,
+			    bt->dst_cap, bt->d_results, wsb, NULL);
+		else
+			la_launch_inflate(s, bt->d_src, bt->src_bytes, bt->d_members, n, bt->d_dst, bt->dst_cap,
+			    bt->d_results);
+		prof_close(c, h, s);
+	}
 	h = prof_open(c, "gz_crc32", s);
 	la_launch_gz_verify(s, bt->d_src, bt->src_bytes, bt->d_members, bt->n_members, bt->d_dst,
 	    bt->d_results, !(bt->options & LA_GZ_OPT_NO_VERIFY));

@@ -272,9 +272,25 @@ void la_launch_lz4_expand_fast(hipStream_t s, const uint8_t *d_src, uint64_t src
 void la_launch_inflate(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
     const la_gz_member *d_members, uint32_t n, uint8_t *d_dst, uint64_t dst_cap, la_gz_result *d_results);
 uint64_t la_inflate_lanes_scratch_bytes(uint32_t n);
+/* outputs of the entropy-only launch (la_launch_inflate_symbols): everything
+ * lz4_expand_fast_kernel needs to build the members in its LDS window */
+struct la_inflate_emit {
+	uint8_t *lit;		/* literal bytes, 64 KiB per member */
+	la_lz4_seq *table;	/* LA_LZ4_FAST_MAXSEQ entries per member */
+	la_lz4_block *blocks;	/* [n] literal buffer as the expand kernel's "payload" */
+	uint32_t *out_len;	/* [n] */
+	uint32_t *nseq;		/* [n] */
+	uint32_t *xstatus;	/* [n] 0 = expand it, else skip (member goes to the in-place kernel) */
+	uint32_t *todo;		/* [n] 1 = the in-place kernel must decode this member */
+	uint64_t *dst_off;	/* [n+1] */
+	uint64_t *table_off;	/* [n+1] */
+};
 void la_launch_inflate_lanes(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
     const la_gz_member *d_members, uint32_t n, uint8_t *d_dst, uint64_t dst_cap, la_gz_result *d_results,
-    void *d_scratch);
+    void *d_scratch, const uint32_t *d_only /* NULL: every member */);
+void la_launch_inflate_symbols(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
+    const la_gz_member *d_members, uint32_t n, uint64_t dst_cap, la_gz_result *d_results,
+    void *d_scratch, la_inflate_emit E);
 void la_launch_gz_verify(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
     const la_gz_member *d_members, uint32_t n, const uint8_t *d_dst, la_gz_result *d_results, int verify);
 void la_launch_gz_summary(hipStream_t s, const la_gz_result *d_results, uint32_t n, la_batch_summary *d_summary);

@@ -121,6 +121,7 @@ __device__ __forceinline__ void lb_drop(lane_bits &B, uint32_t n) { B.hold >>= n
 struct lane_code {
 	packed16 count;		/* codes per length 1..15 */
 	uint32_t maxlen;
+	uint32_t first_p, index_p;	/* canonical-walk state after the lengths the fast table covers */
 };
 
 /*
@@ -150,6 +151,16 @@ __device__ int il_build(const uint8_t *lens, int n, lane_code &C, uint16_t *sort
 		p16_add(next_code, l, code & 0x7FFFu);
 	}
 	C.maxlen = (uint32_t)maxlen;
+	{
+		uint32_t fi = 0, ix = 0;
+		for (int l = 1; l <= FAST_BITS; l++) {
+			const uint32_t c = p16_get(C.count, l);
+			ix += c;
+			fi = (fi + c) << 1;
+		}
+		C.first_p = fi;
+		C.index_p = ix;
+	}
 	for (int i = 0; i < (1 << FAST_BITS); i++)
 		fast[i][tid] = 0;
 	if (left < 0)
@@ -185,49 +196,129 @@ __device__ __forceinline__ int il_decode(lane_bits &B, const lane_code &C, const
 		*used = l;
 		return (int)(e >> 4);
 	}
-	/* long or unassigned code: canonical walk, one bit at a time */
-	int codev = 0, first = 0, index = 0;
-	const uint32_t ml = C.maxlen ? C.maxlen : 1;
-	for (uint32_t k = 1; k <= ml; k++) {
-		codev |= (int)(B.hold & 1);
-		lb_drop(B, 1);
-		const int cn = (int)p16_get(C.count, k);
-		if (codev - cn < first) {
-			*used = k;
-			return sorted[index + (codev - first)];
-		}
+	/* Long or unassigned code.  The canonical walk for the lengths the fast table covers
+	 * cannot hit (the table would have had the code) and its state after them does not
+	 * depend on the code: it was precomputed with the table.  The remaining lengths are
+	 * tried in straight-line code on the next 15 bits (every lane of the wave pays for this
+	 * path whenever one lane takes it, so it has no loop and no dynamic counter picks). */
+	const uint32_t rev = __builtin_bitreverse32(lb_peek(B, 15)) >> 17;	/* first bit read = bit 14 */
+	int first = (int)C.first_p, index = (int)C.index_p;
+	int hit_len = 0, hit_idx = 0;
+#pragma unroll
+	for (int k = FAST_BITS + 1; k <= 15; k++) {
+		if (__ballot(hit_len == 0 && (uint32_t)k <= C.maxlen) == 0)
+			break;	/* (wave-uniform) every lane here has its code, or no longer ones exist */
+		const int cn = (int)((C.count.w[k >> 2] >> (16 * (k & 3))) & 0xFFFFu);
+		const int codev = (int)(rev >> (15 - k));
+		const bool hit = hit_len == 0 && (uint32_t)k <= C.maxlen && codev - cn < first;
+		hit_idx = hit ? index + (codev - first) : hit_idx;
+		hit_len = hit ? k : hit_len;
 		index += cn;
-		first += cn;
-		first <<= 1;
-		codev <<= 1;
+		first = (first + cn) << 1;
 	}
-	*used = ml;
+	if (hit_len) {
+		lb_drop(B, (uint32_t)hit_len);
+		*used = (uint32_t)hit_len;
+		return sorted[hit_idx];
+	}
+	{
+		const uint32_t ml = C.maxlen ? C.maxlen : 1;
+		lb_drop(B, ml);
+		*used = ml;
+	}
 	return -2;
 }
 
-__device__ __constant__ uint16_t il_len_base[29] = { 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31,
-	35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258 };
-__device__ __constant__ uint8_t il_len_extra[29] = { 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2,
-	3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0 };
-__device__ __constant__ uint16_t il_dist_base[30] = { 1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193,
-	257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577 };
-__device__ __constant__ uint8_t il_dist_extra[30] = { 0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6,
-	7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13 };
+/* length / distance symbol -> base value and extra bits, by arithmetic (RFC 1951 3.2.5):
+ * no table in memory, a divergent table read costs more than these few operations */
+__device__ __forceinline__ void il_len_sym(uint32_t sy, uint32_t &base, uint32_t &extra)
+{
+	extra = sy < 8 ? 0u : sy == 28 ? 0u : (sy - 4) >> 2;
+	base = sy < 8 ? 3u + sy : sy == 28 ? 258u : ((4u + (sy & 3u)) << extra) + 3u;
+}
+__device__ __forceinline__ void il_dist_sym(uint32_t ds, uint32_t &base, uint32_t &extra)
+{
+	extra = ds < 4 ? 0u : (ds >> 1) - 1u;
+	base = ds < 4 ? ds + 1u : ((2u + (ds & 1u)) << extra) + 1u;
+}
+
 __device__ __constant__ uint8_t il_clc_order[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
 
 /* the symbol just taken needed bits the member does not have */
 #define IL_CHECK_TRUNC()  do { if (lb_avail(B) < 0) { status = LA_ST_GZ_TRUNCATED; goto done; } } while (0)
 
+/*
+ * EMIT = false: the member is decoded in place (literals and match copies go straight to the
+ * slab).  `only`, if given, restricts the launch to the members it flags.
+ *
+ * EMIT = true: entropy decoding only.  The lane writes the member's LITERALS densely into a
+ * buffer of their own and every match as an 8-byte sequence {literal source, literal run
+ * length, output position, distance} -- the very table the LZ4 parse kernel produces -- and
+ * lz4_expand_fast_kernel then builds the output in its LDS window (literals with coalesced
+ * loads, matches with LDS copies) instead of this lane chasing its own output through global
+ * memory one match at a time.  Members the LDS-window kernel cannot take (slot above 64 KiB,
+ * more than LA_LZ4_FAST_MAXSEQ matches) are flagged in E.todo for an EMIT = false launch.
+ */
+template <bool EMIT>
 __global__ __launch_bounds__(IL_THREADS) void inflate_lanes_kernel(const uint8_t *__restrict__ src,
     uint64_t src_bytes, const la_gz_member *__restrict__ members, uint32_t n, uint8_t *dst,
-    uint64_t dst_cap, la_gz_result *__restrict__ results, uint8_t *scratch)
+    uint64_t dst_cap, la_gz_result *__restrict__ results, uint8_t *scratch, const uint32_t *__restrict__ only,
+    la_inflate_emit E)
 {
 	__shared__ il_lds T;
 	const int tid = threadIdx.x;
 	const uint32_t mi = blockIdx.x * IL_THREADS + tid;
 	if (mi >= n)
 		return;
+	if (!EMIT && only && only[mi] == 0)
+		return;
 	const la_gz_member m = members[mi];
+	if (EMIT) {
+		E.dst_off[mi] = m.dst_off;
+		E.table_off[mi] = (uint64_t)mi * LA_LZ4_FAST_MAXSEQ;
+		if (mi + 1 == n) {
+			E.dst_off[n] = m.dst_off + m.dst_cap;
+			E.table_off[n] = (uint64_t)n * LA_LZ4_FAST_MAXSEQ;
+		}
+		if (m.dst_cap > 65536u) {	/* the LDS window holds 64 KiB */
+			E.todo[mi] = 1;
+			E.xstatus[mi] = 1;
+			E.out_len[mi] = 0;
+			E.nseq[mi] = 0;
+			return;
+		}
+	}
+	/* EMIT state: literal and sequence counts, current literal run */
+	uint64_t l0 = 0, l1 = 0, pend = 0;
+	uint32_t nl = 0, ns = 0, run_src = 0, run_dst = 0;
+	bool overflow = false;
+	uint8_t *const litb = EMIT ? E.lit + (uint64_t)mi * 65536u : nullptr;
+	uint64_t *const tabp = EMIT ? (uint64_t *)(E.table + (uint64_t)mi * LA_LZ4_FAST_MAXSEQ) : nullptr;
+/* Literals leave through a 16-byte register accumulator and table entries in pairs: fewer,
+ * wider stores.  (Measured: plain 1-byte / 8-byte stores are 25 % slower -- the memory
+ * counter the bit-buffer refills wait on counts stores too.) */
+#define IL_PUT_LIT(byte_)                                                                         \
+	do {                                                                                      \
+		const uint32_t pos_ = nl & 15u;                                                   \
+		if (pos_ < 8) l0 |= (uint64_t)(byte_) << (8 * pos_);                              \
+		else l1 |= (uint64_t)(byte_) << (8 * (pos_ - 8));                                 \
+		nl++;                                                                             \
+		if ((nl & 15u) == 0) {                                                            \
+			*(uint4 *)(litb + nl - 16) = make_uint4((uint32_t)l0, (uint32_t)(l0 >> 32), (uint32_t)l1, (uint32_t)(l1 >> 32)); \
+			l0 = l1 = 0;                                                              \
+		}                                                                                 \
+	} while (0)
+#define IL_PUT_SEQ(off_)                                                                          \
+	do {                                                                                      \
+		if (ns >= LA_LZ4_FAST_MAXSEQ) { overflow = true; goto done; }                     \
+		const uint64_t e_ = (uint64_t)(run_src | ((nl - run_src) << 16)) |                 \
+		    ((uint64_t)(run_dst | ((uint32_t)(off_) << 16)) << 32);                       \
+		if (ns & 1u)                                                                      \
+			*(uint4 *)(tabp + ns - 1) = make_uint4((uint32_t)pend, (uint32_t)(pend >> 32), (uint32_t)e_, (uint32_t)(e_ >> 32)); \
+		else                                                                              \
+			pend = e_;                                                                \
+		ns++;                                                                             \
+	} while (0)
 	uint8_t *lens = scratch + (uint64_t)mi * IL_SCRATCH_PER_LANE;		/* [320] */
 	uint16_t *sorted_ll = (uint16_t *)(lens + 320);				/* [288] */
 	uint16_t *sorted_d = sorted_ll + 288;					/* [32] */
@@ -270,8 +361,15 @@ __global__ __launch_bounds__(IL_THREADS) void inflate_lanes_kernel(const uint8_t
 			const uint32_t avail = B.ip < B.iend ? B.iend - B.ip : 0;
 			const uint32_t take = len < avail ? len : avail;
 			if (op + take > cap) { status = LA_ST_GZ_OUT_FULL; goto done; }
-			for (uint32_t j = 0; j < take; j++)
-				d[op + j] = B.s[B.ip + j];
+			if (EMIT) {
+				for (uint32_t j = 0; j < take; j++) {
+					const uint32_t by = B.s[B.ip + j];
+					IL_PUT_LIT(by);
+				}
+			} else {
+				for (uint32_t j = 0; j < take; j++)
+					d[op + j] = B.s[B.ip + j];
+			}
 			op += take;
 			lb_seek(B, B.ip + take);
 			if (take < len) { status = LA_ST_GZ_TRUNCATED; goto done; }
@@ -365,26 +463,39 @@ __global__ __launch_bounds__(IL_THREADS) void inflate_lanes_kernel(const uint8_t
 				if (sym < 0) { status = LA_ST_GZ_DATA; goto done; }
 				if (sym < 256) {
 					if (op >= cap) { status = LA_ST_GZ_OUT_FULL; goto done; }
-					d[op++] = (uint8_t)sym;
+					if (EMIT) {
+						IL_PUT_LIT((uint32_t)sym);
+						op++;
+					} else {
+						d[op++] = (uint8_t)sym;
+					}
 					continue;
 				}
 				if (sym == 256)
 					break;
 				sym -= 257;
 				if (sym >= 29) { status = LA_ST_GZ_DATA; goto done; }
-				uint32_t xb = il_len_extra[sym];
-				const uint32_t length = il_len_base[sym] + lb_peek(B, xb);
+				uint32_t xb, bs;
+				il_len_sym((uint32_t)sym, bs, xb);
+				const uint32_t length = bs + lb_peek(B, xb);
 				lb_drop(B, xb);
 				IL_CHECK_TRUNC();
 				const int ds = il_decode<DT_BITS>(B, CD, sorted_d, T.dt, tid, &used);
 				IL_CHECK_TRUNC();
 				if (ds < 0 || ds >= 30) { status = LA_ST_GZ_DATA; goto done; }
-				xb = il_dist_extra[ds];
-				const uint32_t dist = il_dist_base[ds] + lb_peek(B, xb);
+				il_dist_sym((uint32_t)ds, bs, xb);
+				const uint32_t dist = bs + lb_peek(B, xb);
 				lb_drop(B, xb);
 				IL_CHECK_TRUNC();
 				if (dist > op) { status = LA_ST_GZ_DATA; goto done; }
 				if (op + length > cap) { status = LA_ST_GZ_OUT_FULL; goto done; }
+				if (EMIT) {
+					IL_PUT_SEQ(dist);
+					op += length;
+					run_src = nl;
+					run_dst = op;
+					continue;
+				}
 				uint8_t *o = d + op;
 				const uint8_t *f = o - dist;
 				if (dist >= 16 && op + length + 16 <= cap) {
@@ -426,8 +537,53 @@ done:
 		r.out_len = op;
 		r.consumed = consumed;
 		r.crc32 = 0;
+		if (EMIT) {
+			if (nl - run_src > 0xFFFFu)
+				overflow = true;	/* one literal run of 65536 bytes does not fit the 16-bit table field */
+			if (overflow) {
+				/* more matches than the LDS-window kernel holds: the in-place kernel redoes it */
+				E.todo[mi] = 1;
+				E.xstatus[mi] = 1;
+				E.out_len[mi] = 0;
+				E.nseq[mi] = 0;
+				return;
+			}
+			/* whatever was decoded before an error is output too (bytes before the error are
+			 * delivered): close the table with the literals after the last match */
+			if (nl > run_src && ns < LA_LZ4_FAST_MAXSEQ) {
+				const uint64_t e_ = (uint64_t)(run_src | ((nl - run_src) << 16)) | ((uint64_t)run_dst << 32);
+				if (ns & 1u)
+					*(uint4 *)(tabp + ns - 1) = make_uint4((uint32_t)pend, (uint32_t)(pend >> 32), (uint32_t)e_, (uint32_t)(e_ >> 32));
+				else
+					pend = e_;
+				ns++;
+			} else if (nl > run_src) {
+				E.todo[mi] = 1;
+				E.xstatus[mi] = 1;
+				E.out_len[mi] = 0;
+				E.nseq[mi] = 0;
+				return;
+			}
+			if (ns & 1u)
+				tabp[ns - 1] = pend;
+			if (nl & 15u)
+				*(uint4 *)(litb + (nl & ~15u)) = make_uint4((uint32_t)l0, (uint32_t)(l0 >> 32), (uint32_t)l1, (uint32_t)(l1 >> 32));
+			la_lz4_block bk;
+			bk.src_off = (uint64_t)mi * 65536u;
+			bk.src_len = nl;
+			bk.dst_cap = cap;
+			bk.flags = 0;
+			bk.block_sum = 0;
+			E.blocks[mi] = bk;
+			E.out_len[mi] = op;
+			E.nseq[mi] = ns;
+			E.xstatus[mi] = LA_ST_OK;
+			E.todo[mi] = 0;
+		}
 		results[mi] = r;
 	}
+#undef IL_PUT_LIT
+#undef IL_PUT_SEQ
 }
 
 uint64_t la_inflate_lanes_scratch_bytes(uint32_t n)
@@ -437,9 +593,20 @@ uint64_t la_inflate_lanes_scratch_bytes(uint32_t n)
 
 void la_launch_inflate_lanes(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
     const la_gz_member *d_members, uint32_t n, uint8_t *d_dst, uint64_t dst_cap, la_gz_result *d_results,
-    void *d_scratch)
+    void *d_scratch, const uint32_t *d_only)
 {
 	if (n == 0) return;
-	hipLaunchKernelGGL(inflate_lanes_kernel, dim3((n + IL_THREADS - 1) / IL_THREADS), dim3(IL_THREADS), 0, s,
-	    d_src, src_bytes, d_members, n, d_dst, dst_cap, d_results, (uint8_t *)d_scratch);
+	la_inflate_emit none = {};
+	hipLaunchKernelGGL(inflate_lanes_kernel<false>, dim3((n + IL_THREADS - 1) / IL_THREADS), dim3(IL_THREADS), 0, s,
+	    d_src, src_bytes, d_members, n, d_dst, dst_cap, d_results, (uint8_t *)d_scratch, d_only, none);
+}
+
+void la_launch_inflate_symbols(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
+    const la_gz_member *d_members, uint32_t n, uint64_t dst_cap, la_gz_result *d_results,
+    void *d_scratch, la_inflate_emit E)
+{
+	if (n == 0) return;
+	hipLaunchKernelGGL(inflate_lanes_kernel<true>, dim3((n + IL_THREADS - 1) / IL_THREADS), dim3(IL_THREADS), 0, s,
+	    d_src, src_bytes, d_members, n, (uint8_t *)nullptr, dst_cap, d_results, (uint8_t *)d_scratch,
+	    (const uint32_t *)nullptr, E);
 }

@@ -440,7 +440,11 @@ __global__ __launch_bounds__(FAST_THREADS, FAST_MIN_WAVES) void lz4_expand_fast_
 								a[j] = lds_ld8(fp + 8 * j);
 							const uint32_t n = mlen < 64 ? mlen : 64;
 							const uint64_t tail = lds_ld8(fp + (n >= 8 ? n - 8 : 0));
-							if (mlen < 8) {
+							if (mlen < 4) {
+								/* 1..3 bytes: only the deflate front end makes these (LZ4 matches are
+								 * at least four bytes long) */
+								lds_st_tail(mp, a[0], mlen);
+							} else if (mlen < 8) {
 								/* 4 <= mlen <= 7: two overlapping 4-byte stores */
 								lds_st4(mp, (uint32_t)a[0]);
 								lds_st4(mp + mlen - 4, (uint32_t)(a[0] >> (8 * (mlen - 4))));

@@ -14,13 +14,16 @@ ST_OK, ST_DATA, ST_TRUNC, ST_BAD_CRC, ST_BAD_ISIZE, ST_FULL, ST_NOTRAILER = 0, 5
 
 
 def gpu_inflate(ctx, bodies, caps, verify=True):
-    """Runs BOTH deflate kernels (wave per member, lane per member) and insists they agree."""
+    """Runs ALL THREE deflate paths (wave per member; lane per member in place; lane per member
+    entropy decode + LDS-window expand with the in-place kernel as its fallback) and insists
+    they agree."""
     a, sa = _gpu_inflate(ctx, bodies, caps, verify, 2)
-    b, sb = _gpu_inflate(ctx, bodies, caps, verify, 4)
     # `consumed` only means something when the deflate stream ended (status OK / trailer verdicts)
     norm = lambda rs: [(st, out, cons if st in (ST_OK, ST_BAD_CRC, ST_BAD_ISIZE, ST_NOTRAILER) else None, crc) for st, out, cons, crc in rs]
-    assert norm(a) == norm(b), "wave-per-member and lane-per-member kernels disagree"
-    assert int(sa["n_bad_units"]) == int(sb["n_bad_units"]) and int(sa["total_out"]) == int(sb["total_out"])
+    for opt, what in ((4, "lane-per-member in-place"), (8, "two-phase (entropy decode + LDS-window expand)")):
+        b, sb = _gpu_inflate(ctx, bodies, caps, verify, opt)
+        assert norm(a) == norm(b), "wave-per-member and %s kernels disagree" % what
+        assert int(sa["n_bad_units"]) == int(sb["n_bad_units"]) and int(sa["total_out"]) == int(sb["total_out"])
     return a, sa
 
 
