@@ -177,7 +177,9 @@ def main_gzip(args):
         assert res.rc == 0 and np.array_equal(out, plain)
         cpu = dict(value=round(reps * plain.size / el / (1 << 20), 1), unit="MiB/s", cores=1, kind="port",
                    sample="%d x %d MiB decoded, oracle gzip filter (inflate + trailer CRC32), %.1f s" % (reps, plain.size >> 20, el))
-    inf_ms = float(np.mean(phase_ms.get("inflate", [float("nan")])))
+    # deflate decode = entropy decode (inflate_symbols) + LDS-window expand (inflate_expand) + in-place
+    # kernel for members the window kernel cannot take (inflate); older single-kernel paths only have the last
+    inf_ms = float(sum(np.mean(phase_ms[k]) for k in ("inflate_symbols", "inflate_expand", "inflate") if k in phase_ms))
     ach = (C_bytes + U_bytes) / (inf_ms * 1e-3) / 1e9
     print(json.dumps({
         "metric": "decompressed MiB/s (whole node), gzip filter, CRC32 verified, bit-exact",
@@ -188,7 +190,7 @@ def main_gzip(args):
                                % (U_bytes / (1 << 30), plan.n),
                    "compressed_bytes_per_gpu": C_bytes, "decoded_bytes_per_gpu": U_bytes},
         "bit_exact": bool(ok), "phases_ms": {k: round(float(np.mean(v)), 3) for k, v in phase_ms.items()},
-        "roofline": {"bound": "hbm", "kernel": "inflate", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": "inflate (symbols + expand)", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                      "algorithmic_bytes": C_bytes + U_bytes},
         "cpu_baseline": cpu}), flush=True)

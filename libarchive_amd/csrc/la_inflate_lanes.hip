@@ -245,7 +245,9 @@ __device__ __forceinline__ void il_dist_sym(uint32_t ds, uint32_t &base, uint32_
 __device__ __constant__ uint8_t il_clc_order[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
 
 /* the symbol just taken needed bits the member does not have */
-#define IL_CHECK_TRUNC()  do { if (lb_avail(B) < 0) { status = LA_ST_GZ_TRUNCATED; goto done; } } while (0)
+/* (bits can only run out once the byte cursor has passed the end of the member: one compare
+ * in the common case) */
+#define IL_CHECK_TRUNC()  do { if (B.ip > B.iend && lb_avail(B) < 0) { status = LA_ST_GZ_TRUNCATED; goto done; } } while (0)
 
 /*
  * EMIT = false: the member is decoded in place (literals and match copies go straight to the
