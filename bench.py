@@ -264,7 +264,7 @@ def main():
     if rank == 0:
         cpu = None
         sample_ok = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is an N=1 measurement
             import oracle_lib as O  # checker / baseline only
             cpu, ref_out = cpu_baseline(S, O, img_u, idx_u, args.cpu_sample_mib)
             got = plan.d_dst[:len(ref_out)].cpu().numpy()

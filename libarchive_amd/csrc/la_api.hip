@@ -274,6 +274,7 @@ struct lz4_ws {
 	uint32_t *nseq;		/* [n] */
 	uint32_t *caps;		/* [n] table capacity per block */
 	uint32_t *sum_status;	/* [n] block-checksum verdicts (merged into the status at the end) */
+	uint32_t *big;		/* [n+1] count + list of blocks with more sequences than one LDS segment holds */
 	uint64_t *table_off;	/* [n+1] */
 	void *scan;		/* scan scratch */
 	la_lz4_seq *table;
@@ -287,6 +288,7 @@ static void lz4_ws_layout(lz4_ws *w, uint8_t *base, uint32_t n, uint64_t src_byt
 	w->nseq = (uint32_t *)(base + o); o += align_up((uint64_t)n * 4, 256);
 	w->caps = (uint32_t *)(base + o); o += align_up((uint64_t)n * 4, 256);
 	w->sum_status = (uint32_t *)(base + o); o += align_up((uint64_t)n * 4, 256);
+	w->big = (uint32_t *)(base + o); o += align_up((uint64_t)(n + 1) * 4, 256);
 	w->table_off = (uint64_t *)(base + o); o += align_up(((uint64_t)n + 1) * 8, 256);
 	w->scan = base + o; o += align_up(la_scan_scratch_bytes(n), 256);
 	/* a non-final sequence takes >= 3 payload bytes; slots are rounded up to 8 entries:
@@ -376,8 +378,16 @@ int la_gpu_lz4_decode(la_gpu_ctx *c, const la_lz4_batch *bt)
 	h = prof_open(c, fast ? "lz4_expand_general" : "lz4_expand", sx);
 	la_launch_lz4_expand_general(sx, bt->d_src, bt->src_bytes, bt->d_blocks, n, bt->d_dst,
 	    bt->dst_cap, bt->d_dst_off, bt->d_out_len, bt->d_block_status, w.nseq,
-	    fast ? LA_LZ4_FAST_MAXSEQ : 0u);
+	    fast ? 0xFFFFFFFEu : 0u);	/* the LDS-window kernel takes every eligible block that got a table */
 	prof_close(c, h, sx);
+	if (fast) {
+		/* eligible blocks with more sequences than one LDS segment: classified on the device,
+		 * shared out over a small grid (a no-op launch when there are none) */
+		h = prof_open(c, "lz4_expand_big", sx);
+		la_launch_lz4_expand_fast_big(sx, bt->d_src, bt->src_bytes, bt->d_blocks, n, bt->d_dst, bt->dst_cap,
+		    bt->d_dst_off, bt->d_out_len, bt->d_block_status, w.nseq, w.table, w.table_off, w.big);
+		prof_close(c, h, sx);
+	}
 	const uint32_t nsl = (fast && n >= 4u * 8192u) ? 4u : 1u;
 	if (bt->n_frames && !verify)
 		HIPCHK(c, hipMemsetAsync(bt->d_frame_status, 0, (size_t)bt->n_frames * sizeof(uint32_t), sx));

@@ -138,13 +138,17 @@ __device__ __forceinline__ seq_t seq_load(const la_lz4_seq *t, uint32_t k)
 #define SEQ_DST(e)     ((uint32_t)(((e) >> 32) & 0xFFFFu))
 #define SEQ_OFF(e)     ((uint32_t)((e) >> 48))
 
-template <uint32_t MAXSEQ>
+/* SEG = false: one workgroup per block of the table, blocks of at most MAXSEQ sequences (the
+ * usual case).  SEG = true: the workgroups share out the few blocks with MORE sequences, listed
+ * by lz4_classify_kernel, and run them in segments of MAXSEQ sequences. */
+template <uint32_t MAXSEQ, bool SEG>
 __global__ __launch_bounds__(FAST_THREADS, FAST_MIN_WAVES) void lz4_expand_fast_kernel(
     const uint8_t *__restrict__ src, uint64_t src_bytes, const la_lz4_block *__restrict__ blocks,
     uint32_t n, uint8_t *__restrict__ dst, uint64_t dst_cap, const uint64_t *__restrict__ dst_off,
     const uint32_t *__restrict__ out_len, uint32_t *status_out,
     const uint32_t *__restrict__ nseq, const la_lz4_seq *__restrict__ table,
-    const uint64_t *__restrict__ table_off)
+    const uint64_t *__restrict__ table_off, const uint32_t *__restrict__ big_list,
+    const uint32_t *__restrict__ big_count)
 {
 	const uint32_t *status = status_out;
 	__shared__ __attribute__((aligned(16))) uint8_t win[16 + 65536 + 96];	/* 16 headroom (literal stores may start 3 bytes early) + 16 alignment shift + slack for over-reads */
@@ -152,21 +156,21 @@ __global__ __launch_bounds__(FAST_THREADS, FAST_MIN_WAVES) void lz4_expand_fast_
 	__shared__ uint32_t donebits[MAXSEQ / 32];	/* one bit per sequence: its match is in the window */
 	__shared__ uint16_t chunk_first[2048 + 8];	/* per 32-byte payload chunk: first sequence with literals in or after it */
 
-	const uint32_t bi = blockIdx.x;
+	auto do_block = [&](const uint32_t bi) __attribute__((always_inline)) {
 	if (bi >= n)
 		return;
 	const la_lz4_block b = blocks[bi];
 	const uint32_t olen = out_len[bi];
-	const uint32_t ns = nseq[bi];
+	const uint32_t ns_all = nseq[bi];
 	const uint64_t doff = dst_off[bi];
-	/* same predicate as the general kernel's skip test */
-	if (status[bi] != LA_ST_OK || olen == 0 || !la_lz4_fast_eligible(b) || ns > MAXSEQ ||
+	/* same predicate as the general kernel's skip test (0xFFFFFFFF: the block has no table) */
+	if (status[bi] != LA_ST_OK || olen == 0 || !la_lz4_fast_eligible(b) || ns_all == 0xFFFFFFFFu ||
 	    doff + olen > dst_cap)
 		return;
 
 	STAMP(0);
 	const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	const la_lz4_seq *tab = table + table_off[bi];
+	const la_lz4_seq *const tab_all = table + table_off[bi];
 	const uint8_t *s = src + b.src_off;
 	const uint64_t s_room = src_bytes - b.src_off;	/* bytes of the image from s on */
 	uint8_t *g_out = dst + doff;
@@ -199,17 +203,39 @@ __global__ __launch_bounds__(FAST_THREADS, FAST_MIN_WAVES) void lz4_expand_fast_
 			}
 		}
 	}
+	/* Blocks with more sequences than the LDS arrays hold are done in SEGMENTS of MAXSEQ
+	 * sequences: prepass, literals and matches per segment, a barrier between segments.
+	 * Sequences of earlier segments are complete by then, so a segment only ever waits on
+	 * its own.  Inside a segment all sequence numbers are local (tab points at its first
+	 * entry); payload chunks are numbered from cb, the chunk in which the segment's
+	 * literals begin (it may be shared with the end of the previous segment: each side
+	 * stores only its own sequences' bytes). */
+	auto segment = [&](const uint32_t kb) __attribute__((always_inline)) {
+	const la_lz4_seq *const tab = tab_all + kb;
+	const uint32_t ns = ns_all - kb < MAXSEQ ? ns_all - kb : MAXSEQ;
+	uint32_t cb = 0, seg_prev_end = 0;
+	if (kb) {
+		const seq_t pvb = seq_load(tab_all, kb - 1);	/* same address in every thread */
+		seg_prev_end = SEQ_LIT_SRC(pvb) + SEQ_LIT_LEN(pvb);
+		cb = seg_prev_end >> 5;
+	}
 	seq_t ent[MAXSTEPS];
 	uint32_t prev_end[MAXSTEPS];
 #pragma unroll
 	for (uint32_t r = 0; r < MAXSTEPS; r++) {
 		const uint32_t k = fast_seq_index(r, wave, lane);
 		ent[r] = k < ns ? seq_load(tab, k) : 0;
-		const seq_t pv = (k > 0 && k < ns) ? seq_load(tab, k - 1) : 0;
+		const seq_t pv = ((k > 0 || kb > 0) && k < ns) ? seq_load(tab_all, kb + k - 1) : 0;
 		prev_end[r] = SEQ_LIT_SRC(pv) + SEQ_LIT_LEN(pv);
 	}
 	if (tid < MAXSEQ / 32)
 		donebits[tid] = 0;
+	if (tid == 0) {
+		/* output position where the segment ends: the match length of its last sequence */
+		dstpos[ns] = kb + ns < ns_all ? (uint16_t)SEQ_DST(seq_load(tab_all, kb + ns)) : (uint16_t)olen;
+		if ((cb << 5) < seg_prev_end)
+			chunk_first[0] = 0;	/* chunk shared with the previous segment: this side starts with its first sequence */
+	}
 	/* chunk_first[c] = first sequence whose literals end beyond payload offset 32c */
 #pragma unroll
 	for (uint32_t r = 0; r < MAXSTEPS; r++) {
@@ -217,10 +243,10 @@ __global__ __launch_bounds__(FAST_THREADS, FAST_MIN_WAVES) void lz4_expand_fast_
 		if (k < ns) {
 			const uint32_t le = SEQ_LIT_SRC(ent[r]) + SEQ_LIT_LEN(ent[r]);
 			for (uint32_t c = (prev_end[r] + 31) >> 5; (c << 5) < le; c++)
-				chunk_first[c] = (uint16_t)k;
+				chunk_first[c - cb] = (uint16_t)k;
 			dstpos[k] = (uint16_t)SEQ_DST(ent[r]);
 			if (k + 1 == ns)
-				chunk_first[2048] = (uint16_t)((le + 31) >> 5);	/* chunks from here on hold no literals */
+				chunk_first[2048] = (uint16_t)(((le + 31) >> 5) - cb);	/* chunks from here on hold no literals of this segment */
 		}
 	}
 	__syncthreads();
@@ -239,11 +265,11 @@ __global__ __launch_bounds__(FAST_THREADS, FAST_MIN_WAVES) void lz4_expand_fast_
 		seq_t pe[LBATCH][6];
 #pragma unroll
 		for (int u = 0; u < LBATCH; u++) {
-			const uint32_t c = base + u * FAST_THREADS + tid;
+			const uint32_t c = base + u * FAST_THREADS + tid;	/* chunk number inside the segment */
 			kk[u] = c < nlit_chunks ? (uint32_t)chunk_first[c] : 0xFFFFFFFFu;
-			if (base != 0) {	/* payloads beyond 32 KiB: later chunks are loaded here */
+			if (base != 0 || kb != 0) {	/* payloads beyond 32 KiB, later segments: chunks are loaded here */
 				vv[u][0] = vv[u][1] = vv[u][2] = vv[u][3] = 0;
-				const uint32_t c0 = c << 5;
+				const uint32_t c0 = (cb + c) << 5;
 				if (c < nlit_chunks) {
 					if ((uint64_t)c0 + 32 <= s_room) {
 						const uint4 a = ld_u128(s + c0), bq = ld_u128(s + c0 + 16);
@@ -272,7 +298,7 @@ __global__ __launch_bounds__(FAST_THREADS, FAST_MIN_WAVES) void lz4_expand_fast_
 		for (int u = 0; u < LBATCH; u++) {
 			if (kk[u] == 0xFFFFFFFFu)
 				continue;
-			const uint32_t c0 = (base + u * FAST_THREADS + tid) << 5, c1 = c0 + 32;
+			const uint32_t c0 = (cb + base + u * FAST_THREADS + tid) << 5, c1 = c0 + 32;
 			/* The chunk's eight dwords go out with STATIC register indices: dword m of
 			 * the chunk belongs to at most one literal run (two runs are at least a
 			 * 3-byte sequence header apart), and a whole-dword store may spill up to
@@ -281,15 +307,25 @@ __global__ __launch_bounds__(FAST_THREADS, FAST_MIN_WAVES) void lz4_expand_fast_
 			 * phase M writes after the barrier.  No shifting, no register selects. */
 			const uint32_t dd[8] = { (uint32_t)vv[u][0], (uint32_t)(vv[u][0] >> 32), (uint32_t)vv[u][1], (uint32_t)(vv[u][1] >> 32),
 			    (uint32_t)vv[u][2], (uint32_t)(vv[u][2] >> 32), (uint32_t)vv[u][3], (uint32_t)(vv[u][3] >> 32) };
-			/* returns true when the chunk is finished */
-			auto put = [&](const seq_t e) -> bool {
+			/* returns true when the chunk is finished.  exact_head: the run is the first of a
+			 * later segment -- the match in front of it is FINAL (previous segment), so the
+			 * first dword must not spill backwards: its bytes go out one by one. */
+			auto put = [&](const seq_t e, const bool exact_head) -> bool {
 				const uint32_t ls = SEQ_LIT_SRC(e), le = ls + SEQ_LIT_LEN(e);
 				if (ls >= c1)
 					return true;
 				const uint32_t lo = ls > c0 ? ls : c0, hi = le < c1 ? le : c1;
 				if (hi > lo) {
-					const uint32_t m0 = (lo - c0) >> 2, cnt = ((hi - c0 + 3) >> 2) - m0;
+					uint32_t m0 = (lo - c0) >> 2;
+					const uint32_t mend = (hi - c0 + 3) >> 2;
 					uint8_t *wb = W + SEQ_DST(e) + c0 - ls;	/* wb[p - c0] <-> payload[p]; W has 16 bytes of headroom */
+					if (exact_head && lo == ls && ((lo - c0) & 3u)) {
+						const uint32_t stop = hi < c0 + 4 * m0 + 4 ? hi : c0 + 4 * m0 + 4;
+						for (uint32_t pp = lo; pp < stop; pp++)	/* (once per segment: straight from the image) */
+							wb[pp - c0] = (uint64_t)pp < s_room ? s[pp] : (uint8_t)0;
+						m0++;
+					}
+					const uint32_t cnt = mend > m0 ? mend - m0 : 0;
 #pragma unroll
 					for (uint32_t m = 0; m < 8; m++)
 						if (m - m0 < cnt)
@@ -301,9 +337,9 @@ __global__ __launch_bounds__(FAST_THREADS, FAST_MIN_WAVES) void lz4_expand_fast_
 #pragma unroll
 			for (int t = 0; t < 6; t++)
 				if (!fin)
-					fin = (kk[u] + t >= ns) || put(pe[u][t]);
+					fin = (kk[u] + t >= ns) || put(pe[u][t], kb != 0 && kk[u] + t == 0);
 			for (uint32_t k = kk[u] + 6; !fin && k < ns; k++)	/* more than six sequences touch this chunk: rare */
-				fin = put(seq_load(tab, k));
+				fin = put(seq_load(tab, k), false);
 		}
 	}
 	STAMP(1);
@@ -333,42 +369,45 @@ __global__ __launch_bounds__(FAST_THREADS, FAST_MIN_WAVES) void lz4_expand_fast_
 	 * often touched in its literal part only (a sequence is literals first, match second):
 	 * its entry tells, and then it drops out of the wait -- about a third of all waits,
 	 * and many sequences end up waiting for nothing at all. */
-	uint32_t qlast[MAXSTEPS], hib[MAXSTEPS];
+	uint32_t qlh[MAXSTEPS];	/* last sequence under the source range | last source byte << 16; ~0: none */
 #pragma unroll
 	for (uint32_t r = 0; r < MAXSTEPS; r++) {
 		const uint32_t k = fast_seq_index(r, wave, lane);
 		const uint32_t d = SEQ_DST(ent[r]), mdst = d + SEQ_LIT_LEN(ent[r]), off = SEQ_OFF(ent[r]);
 		const uint32_t s0 = mdst - off;
-		uint32_t next = olen;
-		if (k + 1 < ns)
-			next = dstpos[k + 1];
-		const uint32_t mlen = k < ns ? next - mdst : 0;
-		uint32_t cnt = 0;	/* number of earlier sequences to wait for */
-		qlast[r] = 0xFFFFFFFFu;
-		hib[r] = 0;
+		const uint32_t next = k < ns ? dstpos[k + 1] : 0;	/* dstpos[ns] = where the segment's output ends */
+		const uint32_t mlen = k < ns ? (next - mdst) & 0xFFFFu : 0;	/* (positions are 16-bit: an end at 65536 reads 0) */
+		uint32_t cnt = 0;	/* number of earlier sequences (of this segment) to wait for */
+		qlh[r] = 0xFFFFFFFFu;
 		if (mlen != 0 && s0 < d) {
 			const uint32_t span = mlen < off ? mlen : off;
 			uint32_t hi_byte = s0 + span - 1;
 			if (hi_byte >= d)
 				hi_byte = d - 1;
-			uint32_t qe = qcur[r];
-			while (qe + 1 < k && dstpos[qe + 1] <= hi_byte)
-				qe++;
-			cnt = qe - qcur[r] + 1;
-			qlast[r] = qe;
-			hib[r] = hi_byte;
+			/* sources that end before this segment's first output byte need nothing here:
+			 * earlier segments are complete */
+			if (k > 0 && dstpos[0] <= hi_byte) {
+				uint32_t qe = qcur[r];
+				while (qe + 1 < k && dstpos[qe + 1] <= hi_byte)
+					qe++;
+				cnt = qe - qcur[r] + 1;
+				qlh[r] = qe | (hi_byte << 16);
+			}
 		}
 		qcur[r] = (qcur[r] & 0xFFFFu) | (cnt << 16);
 	}
-	{
-		seq_t le[MAXSTEPS];
 #pragma unroll
-		for (uint32_t r = 0; r < MAXSTEPS; r++)
-			le[r] = qlast[r] != 0xFFFFFFFFu ? seq_load(tab, qlast[r]) : 0;
+	for (uint32_t h = 0; h < MAXSTEPS; h += 4) {	/* four entries in flight at a time: registers */
+		if (h * FAST_THREADS >= ns)
+			break;
+		seq_t le[4];
 #pragma unroll
-		for (uint32_t r = 0; r < MAXSTEPS; r++)
-			if (qlast[r] != 0xFFFFFFFFu && hib[r] < SEQ_DST(le[r]) + SEQ_LIT_LEN(le[r]))
-				qcur[r] -= 1u << 16;	/* source ends inside the literals of the last sequence: its match is not needed */
+		for (uint32_t r = 0; r < 4; r++)
+			le[r] = qlh[h + r] != 0xFFFFFFFFu ? seq_load(tab, qlh[h + r] & 0xFFFFu) : 0;
+#pragma unroll
+		for (uint32_t r = 0; r < 4; r++)
+			if (qlh[h + r] != 0xFFFFFFFFu && (qlh[h + r] >> 16) < SEQ_DST(le[r]) + SEQ_LIT_LEN(le[r]))
+				qcur[h + r] -= 1u << 16;	/* source ends inside the literals of the last sequence: its match is not needed */
 	}
 
 #pragma unroll 1
@@ -385,10 +424,8 @@ __global__ __launch_bounds__(FAST_THREADS, FAST_MIN_WAVES) void lz4_expand_fast_
 			if (r == t) { e = ent[t]; qp = qcur[t]; }
 		const uint32_t off = SEQ_OFF(e);
 		const uint32_t mdst = SEQ_DST(e) + SEQ_LIT_LEN(e);
-		uint32_t next = olen;
-		if (active && k + 1 < ns)
-			next = dstpos[k + 1];
-		const uint32_t mlen = active ? next - mdst : 0;
+		const uint32_t next = active ? dstpos[k + 1] : 0;
+		const uint32_t mlen = active ? (next - mdst) & 0xFFFFu : 0;
 		const uint32_t s0 = mdst - off;
 		uint32_t q = qp & 0xFFFFu;
 		const uint32_t qstop = q + (qp >> 16);	/* exclusive; q == qstop: nothing to wait for */
@@ -505,6 +542,19 @@ __global__ __launch_bounds__(FAST_THREADS, FAST_MIN_WAVES) void lz4_expand_fast_
 	}
 	STAMP(3);
 	__syncthreads();
+	};
+	/* the usual block is one segment: that copy of the body is compiled with kb = 0 folded in
+	 * (and without the register pressure of a loop around it) */
+	if (!SEG) {
+		if (ns_all > MAXSEQ)
+			return;		/* the SEG launch takes it */
+		segment(0u);
+	} else {
+		if (ns_all <= MAXSEQ)
+			return;
+		for (uint32_t kb = 0; kb < ns_all; kb += MAXSEQ)
+			segment(kb);
+	}
 	STAMP(4);
 
 	/* ---- phase F: window -> decoded slab, 16 bytes per lane per step ---- */
@@ -521,6 +571,29 @@ __global__ __launch_bounds__(FAST_THREADS, FAST_MIN_WAVES) void lz4_expand_fast_
 	if (tail0 + tid < olen)
 		g_out[tail0 + tid] = W[tail0 + tid];
 	STAMP(5);
+	};	/* do_block */
+	if (!SEG) {
+		do_block(blockIdx.x);
+	} else {
+		const uint32_t cnt = *big_count;
+		for (uint32_t li = blockIdx.x; li < cnt; li += gridDim.x) {
+			do_block(big_list[li]);
+			__syncthreads();	/* the window is reused */
+		}
+	}
+}
+
+/* blocks the SEG launch must take: eligible, with a table, more than MAXSEQ sequences */
+__global__ __launch_bounds__(256) void lz4_classify_kernel(const la_lz4_block *__restrict__ blocks, uint32_t n,
+    const uint32_t *__restrict__ status, const uint32_t *__restrict__ nseq, uint32_t *__restrict__ big_list,
+    uint32_t *__restrict__ big_count)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n)
+		return;
+	const uint32_t ns = nseq[i];
+	if (ns != 0xFFFFFFFFu && ns > LA_LZ4_FAST_MAXSEQ && status[i] == LA_ST_OK && la_lz4_fast_eligible(blocks[i]))
+		big_list[atomicAdd(big_count, 1u)] = i;
 }
 
 #ifdef LA_DIAG
@@ -537,7 +610,24 @@ void la_launch_lz4_expand_fast(hipStream_t s, const uint8_t *d_src, uint64_t src
     const uint32_t *d_nseq, const la_lz4_seq *d_table, const uint64_t *d_table_off)
 {
 	if (n == 0) return;
-	hipLaunchKernelGGL(lz4_expand_fast_kernel<LA_LZ4_FAST_MAXSEQ>, dim3(n), dim3(FAST_THREADS), 0, s,
+	hipLaunchKernelGGL((lz4_expand_fast_kernel<LA_LZ4_FAST_MAXSEQ, false>), dim3(n), dim3(FAST_THREADS), 0, s,
 	    d_src, src_bytes, d_blocks, n, d_dst, dst_cap, d_dst_off, d_out_len, d_status, d_nseq,
-	    d_table, d_table_off);
+	    d_table, d_table_off, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
+}
+
+/* blocks with more than LA_LZ4_FAST_MAXSEQ sequences, over the WHOLE table: classify + a small
+ * grid that shares them out.  d_big: n + 1 words of workspace (count first). */
+void la_launch_lz4_expand_fast_big(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
+    const la_lz4_block *d_blocks, uint32_t n, uint8_t *d_dst, uint64_t dst_cap,
+    const uint64_t *d_dst_off, const uint32_t *d_out_len, uint32_t *d_status,
+    const uint32_t *d_nseq, const la_lz4_seq *d_table, const uint64_t *d_table_off, uint32_t *d_big)
+{
+	if (n == 0) return;
+	(void)hipMemsetAsync(d_big, 0, sizeof(uint32_t), s);
+	hipLaunchKernelGGL(lz4_classify_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_blocks, n, d_status, d_nseq,
+	    d_big + 1, d_big);
+	const uint32_t grid = n < 1024u ? n : 1024u;
+	hipLaunchKernelGGL((lz4_expand_fast_kernel<LA_LZ4_FAST_MAXSEQ, true>), dim3(grid), dim3(FAST_THREADS), 0, s,
+	    d_src, src_bytes, d_blocks, n, d_dst, dst_cap, d_dst_off, d_out_len, d_status, d_nseq,
+	    d_table, d_table_off, (const uint32_t *)(d_big + 1), (const uint32_t *)d_big);
 }

@@ -89,8 +89,9 @@ def test_real_compressor_blocks_and_overlaps(gpu_ctx):
     assert (rc, msg) == (0, "") and out == plain
 
 
-def test_many_short_sequences_route_to_general_kernel(gpu_ctx):
-    """> 4096 sequences in one 64 KiB block: beyond the LDS-window kernel's table."""
+def test_many_short_sequences_take_the_segmented_kernel(gpu_ctx):
+    """> 4096 sequences in one 64 KiB block (13 107 here): more than one LDS segment of the
+    window kernel; such blocks are listed on the device and expanded in segments."""
     rnd = random.Random(4)
     seqs = bytearray()
     plain = bytearray()
