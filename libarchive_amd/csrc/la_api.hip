@@ -441,14 +441,15 @@ int la_gpu_gzip_decode(la_gpu_ctx *c, const la_gz_batch *bt)
 	const uint32_t n = bt->n_members;
 	uint8_t *wsb = NULL;
 	la_inflate_emit E = {};
+	uint32_t *gz_big = NULL;
 	if (lanes) {
 		uint64_t need = align_up(la_inflate_lanes_scratch_bytes(n), 256);
 		const uint64_t o_scratch = 0;
 		uint64_t o = need;
-		uint64_t o_lit = 0, o_tab = 0, o_blk = 0, o_olen = 0, o_nseq = 0, o_xst = 0, o_todo = 0, o_doff = 0, o_toff = 0;
+		uint64_t o_lit = 0, o_tab = 0, o_blk = 0, o_olen = 0, o_nseq = 0, o_xst = 0, o_todo = 0, o_doff = 0, o_toff = 0, o_big = 0;
 		if (two_phase) {
 			o_lit = o;  o += align_up((uint64_t)n * 65536u, 256);
-			o_tab = o;  o += align_up((uint64_t)n * LA_LZ4_FAST_MAXSEQ * sizeof(la_lz4_seq), 256);
+			o_tab = o;  o += align_up((uint64_t)n * LA_INFLATE_MAXSEQ * sizeof(la_lz4_seq), 256);
 			o_blk = o;  o += align_up((uint64_t)n * sizeof(la_lz4_block), 256);
 			o_olen = o; o += align_up((uint64_t)n * 4, 256);
 			o_nseq = o; o += align_up((uint64_t)n * 4, 256);
@@ -456,6 +457,7 @@ int la_gpu_gzip_decode(la_gpu_ctx *c, const la_gz_batch *bt)
 			o_todo = o; o += align_up((uint64_t)n * 4, 256);
 			o_doff = o; o += align_up((uint64_t)(n + 1) * 8, 256);
 			o_toff = o; o += align_up((uint64_t)(n + 1) * 8, 256);
+			o_big = o;  o += align_up((uint64_t)(n + 1) * 4, 256);
 		}
 		if (o > c->ws_bytes) {
 			int rc = la_gpu_reserve(c, o);
@@ -473,6 +475,7 @@ int la_gpu_gzip_decode(la_gpu_ctx *c, const la_gz_batch *bt)
 			E.todo = (uint32_t *)(wsb + o_todo);
 			E.dst_off = (uint64_t *)(wsb + o_doff);
 			E.table_off = (uint64_t *)(wsb + o_toff);
+			gz_big = (uint32_t *)(wsb + o_big);
 		}
 	}
 	prof_begin(c);
@@ -484,6 +487,9 @@ int la_gpu_gzip_decode(la_gpu_ctx *c, const la_gz_batch *bt)
 		h = prof_open(c, "inflate_expand", s);
 		la_launch_lz4_expand_fast(s, E.lit, (uint64_t)n * 65536u, E.blocks, n, bt->d_dst, bt->dst_cap,
 		    E.dst_off, E.out_len, E.xstatus, E.nseq, E.table, E.table_off);
+		/* members with more matches than one LDS segment holds */
+		la_launch_lz4_expand_fast_big(s, E.lit, (uint64_t)n * 65536u, E.blocks, n, bt->d_dst, bt->dst_cap,
+		    E.dst_off, E.out_len, E.xstatus, E.nseq, E.table, E.table_off, gz_big);
 		prof_close(c, h, s);
 		/* members the LDS-window kernel cannot take: decoded in place */
 		h = prof_open(c, "inflate", s);

@@ -240,7 +240,8 @@ struct la_lz4_seq {	/* one LZ4 sequence, 8 bytes, written by the parse kernel */
 };
 /* match length of sequence k = (k+1 < nseq ? seq[k+1].dst : out_len) - (dst + lit_len) */
 
-#define LA_LZ4_FAST_MAXSEQ 4096u	/* sequences per block the LDS-window kernel holds */
+#define LA_LZ4_FAST_MAXSEQ 4096u	/* sequences per block the LDS-window kernel holds (per segment) */
+#define LA_INFLATE_MAXSEQ 12288u	/* table entries per deflate member in the two-phase path (three segments) */
 
 /* blocks the LDS-window kernel may take: compressed, independent, window <= 64 KiB */
 __host__ __device__ __forceinline__ bool la_lz4_fast_eligible(const la_lz4_block &b)
@@ -281,7 +282,7 @@ uint64_t la_inflate_lanes_scratch_bytes(uint32_t n);
  * lz4_expand_fast_kernel needs to build the members in its LDS window */
 struct la_inflate_emit {
 	uint8_t *lit;		/* literal bytes, 64 KiB per member */
-	la_lz4_seq *table;	/* LA_LZ4_FAST_MAXSEQ entries per member */
+	la_lz4_seq *table;	/* LA_INFLATE_MAXSEQ entries per member */
 	la_lz4_block *blocks;	/* [n] literal buffer as the expand kernel's "payload" */
 	uint32_t *out_len;	/* [n] */
 	uint32_t *nseq;		/* [n] */

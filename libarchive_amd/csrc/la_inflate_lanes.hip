@@ -259,7 +259,7 @@ __device__ __constant__ uint8_t il_clc_order[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 
  * lz4_expand_fast_kernel then builds the output in its LDS window (literals with coalesced
  * loads, matches with LDS copies) instead of this lane chasing its own output through global
  * memory one match at a time.  Members the LDS-window kernel cannot take (slot above 64 KiB,
- * more than LA_LZ4_FAST_MAXSEQ matches) are flagged in E.todo for an EMIT = false launch.
+ * more than LA_INFLATE_MAXSEQ matches) are flagged in E.todo for an EMIT = false launch.
  */
 template <bool EMIT>
 __global__ __launch_bounds__(IL_THREADS) void inflate_lanes_kernel(const uint8_t *__restrict__ src,
@@ -277,10 +277,10 @@ __global__ __launch_bounds__(IL_THREADS) void inflate_lanes_kernel(const uint8_t
 	const la_gz_member m = members[mi];
 	if (EMIT) {
 		E.dst_off[mi] = m.dst_off;
-		E.table_off[mi] = (uint64_t)mi * LA_LZ4_FAST_MAXSEQ;
+		E.table_off[mi] = (uint64_t)mi * LA_INFLATE_MAXSEQ;
 		if (mi + 1 == n) {
 			E.dst_off[n] = m.dst_off + m.dst_cap;
-			E.table_off[n] = (uint64_t)n * LA_LZ4_FAST_MAXSEQ;
+			E.table_off[n] = (uint64_t)n * LA_INFLATE_MAXSEQ;
 		}
 		if (m.dst_cap > 65536u) {	/* the LDS window holds 64 KiB */
 			E.todo[mi] = 1;
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(IL_THREADS) void inflate_lanes_kernel(const uint8_t
 	uint32_t nl = 0, ns = 0, run_src = 0, run_dst = 0;
 	bool overflow = false;
 	uint8_t *const litb = EMIT ? E.lit + (uint64_t)mi * 65536u : nullptr;
-	uint64_t *const tabp = EMIT ? (uint64_t *)(E.table + (uint64_t)mi * LA_LZ4_FAST_MAXSEQ) : nullptr;
+	uint64_t *const tabp = EMIT ? (uint64_t *)(E.table + (uint64_t)mi * LA_INFLATE_MAXSEQ) : nullptr;
 /* Literals leave through a 16-byte register accumulator and table entries in pairs: fewer,
  * wider stores.  (Measured: plain 1-byte / 8-byte stores are 25 % slower -- the memory
  * counter the bit-buffer refills wait on counts stores too.) */
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(IL_THREADS) void inflate_lanes_kernel(const uint8_t
 	} while (0)
 #define IL_PUT_SEQ(off_)                                                                          \
 	do {                                                                                      \
-		if (ns >= LA_LZ4_FAST_MAXSEQ) { overflow = true; goto done; }                     \
+		if (ns >= LA_INFLATE_MAXSEQ) { overflow = true; goto done; }                     \
 		const uint64_t e_ = (uint64_t)(run_src | ((nl - run_src) << 16)) |                 \
 		    ((uint64_t)(run_dst | ((uint32_t)(off_) << 16)) << 32);                       \
 		if (ns & 1u)                                                                      \
@@ -552,7 +552,7 @@ done:
 			}
 			/* whatever was decoded before an error is output too (bytes before the error are
 			 * delivered): close the table with the literals after the last match */
-			if (nl > run_src && ns < LA_LZ4_FAST_MAXSEQ) {
+			if (nl > run_src && ns < LA_INFLATE_MAXSEQ) {
 				const uint64_t e_ = (uint64_t)(run_src | ((nl - run_src) << 16)) | ((uint64_t)run_dst << 32);
 				if (ns & 1u)
 					*(uint4 *)(tabp + ns - 1) = make_uint4((uint32_t)pend, (uint32_t)(pend >> 32), (uint32_t)e_, (uint32_t)(e_ >> 32));

@@ -95,6 +95,31 @@ def test_valid_members_all_block_types(gpu_ctx):
     assert int(sm["n_bad_units"]) == 0 and int(sm["total_out"]) == sum(len(d) for d in datas)
 
 
+def test_members_with_many_short_matches(gpu_ctx):
+    """64 KiB members of text-like data: thousands of short matches per member -- more than one
+    LDS segment of the window kernel (4096), and for the densest ones more than the two-phase
+    path's table holds (12288), which must fall back to the in-place kernel."""
+    rnd = random.Random(77)
+    datas = []
+    for t in range(24):
+        nwords = (6, 20, 200, 2000)[t % 4]
+        words = [bytes(rnd.choice(b"abcdefghijklmnopqrstuvwxyz ") for _ in range(rnd.randint(2, 7))) for _ in range(nwords)]
+        d = bytearray()
+        while len(d) < 65536:
+            d += rnd.choice(words)
+        datas.append(bytes(d[:65536]))
+    # three-byte matches only: the densest sequence table a deflate stream can have
+    tri = bytearray(rnd.randbytes(3000))
+    while len(tri) < 65536:
+        a = rnd.randrange(0, len(tri) - 3)
+        tri += tri[a:a + 3] + rnd.randbytes(1)
+    datas.append(bytes(tri[:65536]))
+    bodies = [deflate(d, 9 if i % 2 else 6) + trailer(d) for i, d in enumerate(datas)]
+    res, sm = gpu_inflate(gpu_ctx, bodies, [len(d) for d in datas])
+    for (st, out, cons, crc), d in zip(res, datas):
+        assert (st, out, crc) == (ST_OK, d, zlib.crc32(d) & 0xFFFFFFFF)
+
+
 def test_trailer_verdicts(gpu_ctx):
     d = b"The quick brown fox " * 90
     c = deflate(d)
