@@ -27,7 +27,7 @@
 #define IL_THREADS 256
 #endif
 #ifndef LL_BITS
-#define LL_BITS 8
+#define LL_BITS 7
 #endif
 #define DT_BITS 6
 #ifndef IL_LIT_BURST
@@ -36,9 +36,19 @@
 #define IL_SCRATCH_PER_LANE 1024u	/* bytes of global scratch per member: lens[320] + sorted symbols u16[320] + pad */
 
 /* ---- per-lane LDS tables, transposed: element e of lane t at [e][t] ---- */
+/* 608 bytes per lane = 152 KiB per 256-lane workgroup (one workgroup per CU):
+ *   ll  fast table of the literal/length code, LL_BITS wide, entry = symbol << 4 | length
+ *   sl  the literal/length symbols in canonical code order (low byte; symbols above 255 come
+ *       last within their length, the lane keeps that boundary per length in registers), so
+ *       a code longer than the fast table still resolves without a trip to global memory --
+ *       every lane of the wave waits for such a trip whenever one lane needs it, and with
+ *       64 lanes one nearly always does
+ *   dt  fast table of the distance code (and, while a block header is read, of the
+ *       code-length code), DT_BITS wide, entry = symbol << 3 | length */
 struct il_lds {
 	uint16_t ll[1 << LL_BITS][IL_THREADS];
-	uint16_t dt[1 << DT_BITS][IL_THREADS];
+	uint8_t sl[288][IL_THREADS];
+	uint8_t dt[1 << DT_BITS][IL_THREADS];
 };
 
 /* 16 counters of up to 15 bits each, packed 4 per u64 (dynamic index without scratch) */
@@ -125,6 +135,7 @@ struct lane_code {
 	packed16 count;		/* codes per length 1..15 */
 	uint32_t maxlen;
 	uint32_t first_p, index_p;	/* canonical-walk state after the lengths the fast table covers */
+	packed16 nlow;		/* literal/length code only: symbols below 256 per length */
 };
 
 /*
@@ -132,11 +143,12 @@ struct lane_code {
  * list (global scratch, for codes longer than the fast table) and the LDS fast table.
  * Returns 0 complete, >0 incomplete, <0 over-subscribed.
  */
-template <int FAST_BITS>
+template <int FAST_BITS, bool LL>
 __device__ int il_build(const uint8_t *lens, int n, lane_code &C, uint16_t *sorted,
-    uint16_t (*fast)[IL_THREADS], int tid)
+    il_lds &T, int tid)
 {
 	p16_zero(C.count);
+	p16_zero(C.nlow);
 	for (int i = 0; i < n; i++)
 		p16_add(C.count, lens[i], 1);
 	int left = 1, maxlen = 0;
@@ -164,8 +176,9 @@ __device__ int il_build(const uint8_t *lens, int n, lane_code &C, uint16_t *sort
 		C.first_p = fi;
 		C.index_p = ix;
 	}
-	for (int i = 0; i < (1 << FAST_BITS); i++)
-		fast[i][tid] = 0;
+	for (int i = 0; i < (1 << FAST_BITS); i++) {
+		if (LL) T.ll[i][tid] = 0; else T.dt[i][tid] = 0;
+	}
 	if (left < 0)
 		return -1;
 	for (int sy = 0; sy < n; sy++) {
@@ -173,14 +186,21 @@ __device__ int il_build(const uint8_t *lens, int n, lane_code &C, uint16_t *sort
 		if (l == 0) continue;
 		const uint32_t pos = p16_get(next_off, l);
 		p16_add(next_off, l, 1);
-		sorted[pos] = (uint16_t)sy;
+		if (LL) {
+			T.sl[pos][tid] = (uint8_t)sy;
+			if (sy < 256)
+				p16_add(C.nlow, l, 1);
+		} else {
+			sorted[pos] = (uint16_t)sy;
+		}
 		const uint32_t cw = p16_get(next_code, l);
 		p16_add(next_code, l, 1);
 		if (l <= (uint32_t)FAST_BITS) {
 			const uint32_t r = __builtin_bitreverse32(cw) >> (32 - l);
-			const uint16_t e = (uint16_t)((sy << 4) | l);
-			for (uint32_t idx = r; idx < (1u << FAST_BITS); idx += (1u << l))
-				fast[idx][tid] = e;
+			for (uint32_t idx = r; idx < (1u << FAST_BITS); idx += (1u << l)) {
+				if (LL) T.ll[idx][tid] = (uint16_t)((sy << 4) | l);
+				else T.dt[idx][tid] = (uint8_t)((sy << 3) | l);
+			}
 		}
 	}
 	return left;
@@ -188,16 +208,16 @@ __device__ int il_build(const uint8_t *lens, int n, lane_code &C, uint16_t *sort
 
 /* decode one symbol; *used = bits consumed.  >= 0 symbol, -2 unassigned code.
  * The caller checks availability of the consumed bits afterwards. */
-template <int FAST_BITS>
+template <int FAST_BITS, bool LL>
 __device__ __forceinline__ int il_decode(lane_bits &B, const lane_code &C, const uint16_t *sorted,
-    uint16_t (*fast)[IL_THREADS], int tid, uint32_t *used)
+    const il_lds &T, int tid, uint32_t *used)
 {
-	const uint32_t e = fast[lb_peek(B, FAST_BITS)][tid];
-	const uint32_t l = e & 15;
+	const uint32_t e = LL ? (uint32_t)T.ll[lb_peek(B, FAST_BITS)][tid] : (uint32_t)T.dt[lb_peek(B, FAST_BITS)][tid];
+	const uint32_t l = LL ? (e & 15u) : (e & 7u);
 	if (l) {
 		lb_drop(B, l);
 		*used = l;
-		return (int)(e >> 4);
+		return (int)(LL ? (e >> 4) : (e >> 3));
 	}
 	/* Long or unassigned code.  The canonical walk for the lengths the fast table covers
 	 * cannot hit (the table would have had the code) and its state after them does not
@@ -206,7 +226,7 @@ __device__ __forceinline__ int il_decode(lane_bits &B, const lane_code &C, const
 	 * path whenever one lane takes it, so it has no loop and no dynamic counter picks). */
 	const uint32_t rev = __builtin_bitreverse32(lb_peek(B, 15)) >> 17;	/* first bit read = bit 14 */
 	int first = (int)C.first_p, index = (int)C.index_p;
-	int hit_len = 0, hit_idx = 0;
+	int hit_len = 0, hit_idx = 0, hit_hi = 0;
 #pragma unroll
 	for (int k = FAST_BITS + 1; k <= 15; k++) {
 		if (__ballot(hit_len == 0 && (uint32_t)k <= C.maxlen) == 0)
@@ -215,6 +235,8 @@ __device__ __forceinline__ int il_decode(lane_bits &B, const lane_code &C, const
 		const int codev = (int)(rev >> (15 - k));
 		const bool hit = hit_len == 0 && (uint32_t)k <= C.maxlen && codev - cn < first;
 		hit_idx = hit ? index + (codev - first) : hit_idx;
+		if (LL)	/* symbols above 255 are the last ones of their length */
+			hit_hi = hit ? ((codev - first) >= (int)((C.nlow.w[k >> 2] >> (16 * (k & 3))) & 0xFFFFu) ? 256 : 0) : hit_hi;
 		hit_len = hit ? k : hit_len;
 		index += cn;
 		first = (first + cn) << 1;
@@ -222,6 +244,8 @@ __device__ __forceinline__ int il_decode(lane_bits &B, const lane_code &C, const
 	if (hit_len) {
 		lb_drop(B, (uint32_t)hit_len);
 		*used = (uint32_t)hit_len;
+		if (LL)
+			return (int)T.sl[hit_idx][tid] | hit_hi;
 		return sorted[hit_idx];
 	}
 	{
@@ -400,7 +424,7 @@ __global__ __launch_bounds__(IL_THREADS) void inflate_lanes_kernel(const uint8_t
 				}
 				/* code-length code: 19 symbols, <= 7 bits; its fast table borrows the distance table */
 				lane_code CC;
-				const int e = il_build<DT_BITS>(lens, 19, CC, sorted_d, T.dt, tid);
+				const int e = il_build<DT_BITS, false>(lens, 19, CC, sorted_d, T, tid);
 				if (e != 0 && CC.maxlen != 0) { status = LA_ST_GZ_DATA; goto done; }
 				int idx = 0;
 				uint32_t prev = 0;
@@ -418,7 +442,7 @@ __global__ __launch_bounds__(IL_THREADS) void inflate_lanes_kernel(const uint8_t
 					while (idx < nlen + ndist) {
 						lb_refill(B);
 						uint32_t used;
-						const int sym = il_decode<DT_BITS>(B, CC, sorted_d, T.dt, tid, &used);
+						const int sym = il_decode<DT_BITS, false>(B, CC, sorted_d, T, tid, &used);
 						IL_CHECK_TRUNC();
 						if (sym < 0) { status = LA_ST_GZ_DATA; goto done; }
 						if (sym < 16) {
@@ -450,9 +474,9 @@ __global__ __launch_bounds__(IL_THREADS) void inflate_lanes_kernel(const uint8_t
 				if (lens[256] == 0) { status = LA_ST_GZ_DATA; goto done; }
 			}
 			{
-				int e = il_build<LL_BITS>(lens, nlen, CL, sorted_ll, T.ll, tid);
+				int e = il_build<LL_BITS, true>(lens, nlen, CL, sorted_ll, T, tid);
 				if (e < 0 || (e > 0 && CL.maxlen != 1)) { status = LA_ST_GZ_DATA; goto done; }
-				e = il_build<DT_BITS>(lens + nlen, ndist, CD, sorted_d, T.dt, tid);
+				e = il_build<DT_BITS, false>(lens + nlen, ndist, CD, sorted_d, T, tid);
 				if (e < 0 || (e > 0 && CD.maxlen > 1)) { status = LA_ST_GZ_DATA; goto done; }
 			}
 			/* ---- symbols ---- */
@@ -472,7 +496,7 @@ __global__ __launch_bounds__(IL_THREADS) void inflate_lanes_kernel(const uint8_t
 				for (int burst = 0; burst < IL_LIT_BURST; burst++) {
 					if (B.bits < 48)
 						lb_refill(B);
-					sym = il_decode<LL_BITS>(B, CL, sorted_ll, T.ll, tid, &used);
+					sym = il_decode<LL_BITS, true>(B, CL, sorted_ll, T, tid, &used);
 					IL_CHECK_TRUNC();
 					if (sym < 0) { status = LA_ST_GZ_DATA; goto done; }
 					if (sym >= 256)
@@ -499,7 +523,7 @@ __global__ __launch_bounds__(IL_THREADS) void inflate_lanes_kernel(const uint8_t
 				const uint32_t length = bs + lb_peek(B, xb);
 				lb_drop(B, xb);
 				IL_CHECK_TRUNC();
-				const int ds = il_decode<DT_BITS>(B, CD, sorted_d, T.dt, tid, &used);
+				const int ds = il_decode<DT_BITS, false>(B, CD, sorted_d, T, tid, &used);
 				IL_CHECK_TRUNC();
 				if (ds < 0 || ds >= 30) { status = LA_ST_GZ_DATA; goto done; }
 				il_dist_sym((uint32_t)ds, bs, xb);
