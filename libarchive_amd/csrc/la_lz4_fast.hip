@@ -472,9 +472,16 @@ __global__ __launch_bounds__(FAST_THREADS, FAST_MIN_WAVES) void lz4_expand_fast_
 						{
 							/* first 64 bytes: one batch of loads serves short and long matches alike */
 							uint64_t a[8];
-#pragma unroll
-							for (int j = 0; j < 8; j++)
-								a[j] = lds_ld8(fp + 8 * j);
+							/* an LDS instruction costs the same for one lane as for 64: the upper
+							 * half of the batch is only issued when some lane here needs it */
+							a[0] = lds_ld8(fp); a[1] = lds_ld8(fp + 8); a[2] = lds_ld8(fp + 16); a[3] = lds_ld8(fp + 24);
+							a[4] = a[5] = a[6] = a[7] = 0;
+							if (__ballot(mlen > 32) != 0) {
+								a[4] = lds_ld8(fp + 32); a[5] = lds_ld8(fp + 40);
+								if (__ballot(mlen > 48) != 0) {
+									a[6] = lds_ld8(fp + 48); a[7] = lds_ld8(fp + 56);
+								}
+							}
 							const uint32_t n = mlen < 64 ? mlen : 64;
 							const uint64_t tail = lds_ld8(fp + (n >= 8 ? n - 8 : 0));
 							if (mlen < 4) {
