@@ -49,7 +49,9 @@
  * through ds_bpermute, 35.1), flag look requested one iteration ahead (28.3),
  * speculative source read behind the flag look (27.6), 8-ary search (26.9 from
  * 23.5: more LDS instructions), per-sequence literal copies from global memory
- * (43.6), 256- and 1024-thread workgroups (no gain), longer poll sleeps (+1..4 %).
+ * (43.6), 256- and 1024-thread workgroups (no gain), longer poll sleeps (+1..4 %), every
+ * lane walking through its own sequences at its own pace instead of the wave finishing
+ * slot r first (28.0 from 23.2: the per-lane register picks cost more than the waits).
  */
 #include "la_dev.h"
 
