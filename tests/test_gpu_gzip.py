@@ -19,11 +19,16 @@ def gpu_inflate(ctx, bodies, caps, verify=True):
     they agree."""
     a, sa = _gpu_inflate(ctx, bodies, caps, verify, 2)
     # `consumed` only means something when the deflate stream ended (status OK / trailer verdicts)
-    norm = lambda rs: [(st, out, cons if st in (ST_OK, ST_BAD_CRC, ST_BAD_ISIZE, ST_NOTRAILER) else None, crc) for st, out, cons, crc in rs]
+    # (and a member that does not fit its slot is never delivered -- the filter retries it with a larger
+    # slot -- so how many bytes a kernel had produced when it noticed is not part of the contract)
+    norm = lambda rs: [(st, None, None, None) if st == ST_FULL else
+                       (st, out, cons if st in (ST_OK, ST_BAD_CRC, ST_BAD_ISIZE, ST_NOTRAILER) else None, crc) for st, out, cons, crc in rs]
     for opt, what in ((4, "lane-per-member in-place"), (8, "two-phase (entropy decode + LDS-window expand)")):
         b, sb = _gpu_inflate(ctx, bodies, caps, verify, opt)
         assert norm(a) == norm(b), "wave-per-member and %s kernels disagree" % what
-        assert int(sa["n_bad_units"]) == int(sb["n_bad_units"]) and int(sa["total_out"]) == int(sb["total_out"])
+        assert int(sa["n_bad_units"]) == int(sb["n_bad_units"])
+        if not any(r[0] == ST_FULL for r in a):
+            assert int(sa["total_out"]) == int(sb["total_out"])
     return a, sa
 
 
@@ -160,6 +165,41 @@ def test_mutated_deflate_streams(gpu_ctx):
         want = {0: (ST_OK, ST_NOTRAILER), 1: (ST_TRUNC,), 2: (ST_DATA,)}[rc]
         assert st in want, (i, st, rc)
         assert out == oout, (i, st, rc, len(out), len(oout))
+        if rc == 0:
+            assert cons == ocons
+
+
+def test_mutated_members_in_64k_slots(gpu_ctx):
+    """Mutated / truncated members whose slots are at most 64 KiB: these are the ones the two-phase
+    path (entropy decode + LDS-window expand) takes, so its partial-output and error paths are what
+    is compared here against the oracle and the two other kernels."""
+    rnd = random.Random(11)
+    words = [rnd.randbytes(rnd.randint(1, 12)) for _ in range(40)]
+    bodies, caps, expect = [], [], []
+    for t in range(600):
+        nbytes = rnd.choice([0, 1, 100, 3000, 65536, rnd.randint(0, 65536)])
+        kind = rnd.randrange(4)
+        d = (b"".join(rnd.choice(words) for _ in range(nbytes // 5 + 1))[:nbytes] if kind == 0 else
+             rnd.randbytes(nbytes) if kind == 1 else bytes([t & 255]) * nbytes if kind == 2 else (b"ab" * nbytes)[:nbytes])
+        c = bytearray(deflate(d, rnd.choice([0, 1, 6, 9]),
+                              rnd.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE])))
+        if rnd.random() < 0.6:
+            for _ in range(rnd.randint(1, 3)):
+                if c:
+                    c[rnd.randrange(len(c))] ^= 1 << rnd.randrange(8)
+        if rnd.random() < 0.2 and len(c) > 1:
+            c = c[:rnd.randrange(1, len(c))]
+        cap = rnd.choice([65536, 65536, len(d), max(len(d) - 1, 0), rnd.randint(0, 65536)])
+        c = bytes(c)
+        bodies.append(c)
+        caps.append(cap)
+        expect.append(O.inflate_raw(c, cap))
+    res, _ = gpu_inflate(gpu_ctx, bodies, caps, verify=False)
+    for i, ((st, out, cons, crc), (rc, ocons, oout)) in enumerate(zip(res, expect)):
+        want = {0: (ST_OK, ST_NOTRAILER), 1: (ST_TRUNC,), 2: (ST_DATA,), 3: (ST_FULL,)}[rc]
+        assert st in want, (i, st, rc)
+        if rc != 3:
+            assert out == oout, (i, st, rc, len(out), len(oout))
         if rc == 0:
             assert cons == ocons
 
