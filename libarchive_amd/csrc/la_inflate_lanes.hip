@@ -31,7 +31,7 @@
 #endif
 #define DT_BITS 6
 #ifndef IL_LIT_BURST
-#define IL_LIT_BURST 4
+#define IL_LIT_BURST 3	/* (3 x 15 bits fit the one refill of a burst) */
 #endif
 #define IL_SCRATCH_PER_LANE 1024u	/* bytes of global scratch per member: lens[320] + sorted symbols u16[320] + pad */
 
@@ -492,10 +492,13 @@ __global__ __launch_bounds__(IL_THREADS) void inflate_lanes_kernel(const uint8_t
 				 * match path per literal; unbounded, every lane would wait for the longest
 				 * literal run in the wave (measured: 2.5x slower). */
 				sym = 0;
+				/* ONE refill for the whole burst, taken by every lane (>= 56 bits afterwards):
+				 * three literal/length codes are at most 45 bits, so the burst itself needs no
+				 * per-symbol refill test -- with 64 lanes that test fires for some lane in
+				 * every iteration and the whole wave pays for the refill code each time */
+				lb_refill(B);
 #pragma unroll 1
 				for (int burst = 0; burst < IL_LIT_BURST; burst++) {
-					if (B.bits < 48)
-						lb_refill(B);
 					sym = il_decode<LL_BITS, true>(B, CL, sorted_ll, T, tid, &used);
 					IL_CHECK_TRUNC();
 					if (sym < 0) { status = LA_ST_GZ_DATA; goto done; }
