@@ -318,7 +318,8 @@ __global__ __launch_bounds__(IL_THREADS) void inflate_lanes_kernel(const uint8_t
 		}
 	}
 	/* EMIT state: literal and sequence counts, current literal run */
-	uint64_t l0 = 0, l1 = 0, pend = 0;
+	uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0;	/* literal accumulator */
+	uint64_t pend = 0;
 	uint32_t nl = 0, ns = 0, run_src = 0, run_dst = 0;
 	bool overflow = false;
 	uint8_t *const litb = EMIT ? E.lit + (uint64_t)mi * 65536u : nullptr;
@@ -328,14 +329,16 @@ __global__ __launch_bounds__(IL_THREADS) void inflate_lanes_kernel(const uint8_t
  * counter the bit-buffer refills wait on counts stores too.) */
 #define IL_PUT_LIT(byte_)                                                                         \
 	do {                                                                                      \
-		const uint32_t pos_ = nl & 15u;                                                   \
-		if (pos_ < 8) l0 |= (uint64_t)(byte_) << (8 * pos_);                              \
-		else l1 |= (uint64_t)(byte_) << (8 * (pos_ - 8));                                 \
+		/* the 16-byte accumulator is a shift register: the new byte enters at the top,   \
+		 * after 16 of them the first one has reached byte 0 (four funnel shifts, no      \
+		 * position-dependent branch) */                                                  \
+		q0 = __builtin_amdgcn_alignbit(q1, q0, 8);                                        \
+		q1 = __builtin_amdgcn_alignbit(q2, q1, 8);                                        \
+		q2 = __builtin_amdgcn_alignbit(q3, q2, 8);                                        \
+		q3 = __builtin_amdgcn_alignbit((uint32_t)(byte_), q3, 8);                         \
 		nl++;                                                                             \
-		if ((nl & 15u) == 0) {                                                            \
-			*(uint4 *)(litb + nl - 16) = make_uint4((uint32_t)l0, (uint32_t)(l0 >> 32), (uint32_t)l1, (uint32_t)(l1 >> 32)); \
-			l0 = l1 = 0;                                                              \
-		}                                                                                 \
+		if ((nl & 15u) == 0)                                                              \
+			*(uint4 *)(litb + nl - 16) = make_uint4(q0, q1, q2, q3);                  \
 	} while (0)
 #define IL_PUT_SEQ(off_)                                                                          \
 	do {                                                                                      \
@@ -612,8 +615,17 @@ done:
 			}
 			if (ns & 1u)
 				tabp[ns - 1] = pend;
-			if (nl & 15u)
-				*(uint4 *)(litb + (nl & ~15u)) = make_uint4((uint32_t)l0, (uint32_t)(l0 >> 32), (uint32_t)l1, (uint32_t)(l1 >> 32));
+			if (nl & 15u) {
+				/* the last, partial group sits at the top of the shift register: bring its
+				 * first byte down to byte 0 */
+				for (uint32_t k = nl & 15u; k < 16u; k++) {
+					q0 = __builtin_amdgcn_alignbit(q1, q0, 8);
+					q1 = __builtin_amdgcn_alignbit(q2, q1, 8);
+					q2 = __builtin_amdgcn_alignbit(q3, q2, 8);
+					q3 >>= 8;
+				}
+				*(uint4 *)(litb + (nl & ~15u)) = make_uint4(q0, q1, q2, q3);
+			}
 			la_lz4_block bk;
 			bk.src_off = (uint64_t)mi * 65536u;
 			bk.src_len = nl;
