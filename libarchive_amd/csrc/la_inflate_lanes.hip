@@ -76,15 +76,25 @@ struct lane_bits {
 	uint32_t ip;		/* next byte to feed into hold */
 	uint32_t iend;		/* bytes of the member's span */
 	uint32_t room;		/* bytes from s to the end of the source image */
+	const uint8_t *safe;	/* any address with 8 readable bytes (used instead of an out-of-image one) */
 };
 
+/* Eight input bytes from offset `at`, zeros past the end of the image.  Branch-free in the
+ * common case ON PURPOSE: with a branch around the load the compiler has to merge the loaded
+ * value with the slow path's at the join, which puts the wait for the load right behind it --
+ * and the whole point of `nxt` is that nobody waits for it until the next refill.  The address
+ * is clamped so that the load never leaves the image; what was clamped away is shifted out. */
 __device__ __forceinline__ uint64_t lb_load8(const lane_bits &B, uint32_t at)
 {
+	const bool tiny = B.room < 8;	/* (an image tail shorter than one load: bytes one by one) */
+	const uint32_t a2 = tiny ? 0u : (at < B.room - 8u ? at : B.room - 8u);
+	const uint8_t *ptr = tiny ? B.safe : B.s + a2;
 	uint64_t v;
-	if ((uint64_t)at + 8 <= B.room)
-		__builtin_memcpy(&v, B.s + at, 8);
-	else {
-		v = 0;	/* tail of the image: never read past it */
+	__builtin_memcpy(&v, ptr, 8);
+	const uint32_t drop = at - a2;
+	v = drop >= 8 ? 0 : v >> (8 * drop);
+	if (tiny) {
+		v = 0;
 		for (uint32_t k = 0; k < 8; k++)
 			if (at + k < B.room)
 				v |= (uint64_t)B.s[at + k] << (8 * k);
@@ -357,6 +367,7 @@ __global__ __launch_bounds__(IL_THREADS) void inflate_lanes_kernel(const uint8_t
 	uint32_t status = LA_ST_OK;
 	lane_bits B;
 	B.s = src + m.src_off;
+	B.safe = (const uint8_t *)members;
 	B.iend = m.src_len;
 	{
 		uint64_t room = m.src_off < src_bytes ? src_bytes - m.src_off : 0;
@@ -500,7 +511,7 @@ __global__ __launch_bounds__(IL_THREADS) void inflate_lanes_kernel(const uint8_t
 				 * per-symbol refill test -- with 64 lanes that test fires for some lane in
 				 * every iteration and the whole wave pays for the refill code each time */
 				lb_refill(B);
-#pragma unroll 1
+#pragma unroll	/* (no loop around the burst: a loop head makes the compiler wait for the prefetch there) */
 				for (int burst = 0; burst < IL_LIT_BURST; burst++) {
 					sym = il_decode<LL_BITS, true>(B, CL, sorted_ll, T, tid, &used);
 					IL_CHECK_TRUNC();
