@@ -77,6 +77,7 @@ struct lane_bits {
 	uint32_t iend;		/* bytes of the member's span */
 	uint32_t room;		/* bytes from s to the end of the source image */
 	const uint8_t *safe;	/* any address with 8 readable bytes (used instead of an out-of-image one) */
+	uint32_t nxt_drop;	/* leading bytes of nxt to shift out when it is used */
 };
 
 /* Eight input bytes from offset `at`, zeros past the end of the image.  Branch-free in the
@@ -84,37 +85,43 @@ struct lane_bits {
  * value with the slow path's at the join, which puts the wait for the load right behind it --
  * and the whole point of `nxt` is that nobody waits for it until the next refill.  The address
  * is clamped so that the load never leaves the image; what was clamped away is shifted out. */
-__device__ __forceinline__ uint64_t lb_load8(const lane_bits &B, uint32_t at)
+__device__ __forceinline__ uint64_t lb_load8_raw(const lane_bits &B, uint32_t at, uint32_t *drop)
 {
 	const bool tiny = B.room < 8;	/* (an image tail shorter than one load: bytes one by one) */
 	const uint32_t a2 = tiny ? 0u : (at < B.room - 8u ? at : B.room - 8u);
 	const uint8_t *ptr = tiny ? B.safe : B.s + a2;
 	uint64_t v;
 	__builtin_memcpy(&v, ptr, 8);
-	const uint32_t drop = at - a2;
-	v = drop >= 8 ? 0 : v >> (8 * drop);
+	*drop = at - a2;	/* bytes of v in front of `at`: shifted out when v is USED, not here --
+				 * touching v now would be waiting for the load now */
 	if (tiny) {
 		v = 0;
 		for (uint32_t k = 0; k < 8; k++)
 			if (at + k < B.room)
 				v |= (uint64_t)B.s[at + k] << (8 * k);
+		*drop = 0;
 	}
 	return v;
 }
+__device__ __forceinline__ uint64_t lb_fix(uint64_t raw, uint32_t drop) { return drop >= 8 ? 0 : raw >> (8 * drop); }
 
 __device__ __forceinline__ void lb_start(lane_bits &B)
 {
 	B.hold = 0; B.bits = 0; B.ip = 0;
-	B.cur = lb_load8(B, 0);
-	B.nxt = lb_load8(B, 8);
+	uint32_t d0;
+	B.cur = lb_load8_raw(B, 0, &d0);
+	B.cur = lb_fix(B.cur, d0);
+	B.nxt = lb_load8_raw(B, 8, &B.nxt_drop);
 }
 
 /* re-aim the byte window after the stored-block path moved ip by hand */
 __device__ __forceinline__ void lb_seek(lane_bits &B, uint32_t ip)
 {
 	B.ip = ip; B.bits = 0; B.hold = 0;
-	B.cur = lb_load8(B, ip);
-	B.nxt = lb_load8(B, ip + 8);
+	uint32_t d0;
+	B.cur = lb_load8_raw(B, ip, &d0);
+	B.cur = lb_fix(B.cur, d0);
+	B.nxt = lb_load8_raw(B, ip + 8, &B.nxt_drop);
 }
 
 /* top the buffer up to >= 56 bits.  The bytes come from `cur`; the load that replaces
@@ -128,8 +135,9 @@ __device__ __forceinline__ void lb_refill(lane_bits &B)
 	B.bits += take * 8;
 	if (take) {
 		B.ip += take;
-		B.cur = (B.cur >> (8 * take)) | (B.nxt << (64 - 8 * take));
-		B.nxt = lb_load8(B, B.ip + 8);
+		const uint64_t nx = lb_fix(B.nxt, B.nxt_drop);	/* requested one refill ago */
+		B.cur = (B.cur >> (8 * take)) | (nx << (64 - 8 * take));
+		B.nxt = lb_load8_raw(B, B.ip + 8, &B.nxt_drop);
 	}
 }
 /* bits of REAL input still unread (may be negative when the buffer ran past iend) */
