@@ -51,7 +51,11 @@
  * 23.5: more LDS instructions), per-sequence literal copies from global memory
  * (43.6), 256- and 1024-thread workgroups (no gain), longer poll sleeps (+1..4 %), every
  * lane walking through its own sequences at its own pace instead of the wave finishing
- * slot r first (28.0 from 23.2: the per-lane register picks cost more than the waits).
+ * slot r first (28.0 from 23.2: the per-lane register picks cost more than the waits);
+ * and without effect: 1, 2, 8 or 16 consecutive sequences per lane group instead of 4,
+ * the early payload loads moved behind the table loads / made branch-free (the compiler
+ * waits for them right behind the loads because a byte-wise tail path defines the same
+ * registers; removing that wait changed nothing measurable).
  */
 #include "la_dev.h"
 
