@@ -60,6 +60,12 @@ int         la_gpu_free_host(la_gpu_ctx *ctx, void *h_ptr);
 int         la_gpu_memcpy_h2d(la_gpu_ctx *ctx, void *d_dst, const void *h_src, uint64_t bytes);
 int         la_gpu_memcpy_d2h(la_gpu_ctx *ctx, void *h_dst, const void *d_src, uint64_t bytes);
 
+/* A marker in the stream: la_gpu_mark() notes the point reached so far, la_gpu_wait_mark()
+ * blocks the host until everything queued BEFORE the marker is done -- work queued after it
+ * keeps running (how the filters wait for a slab copy while the next window decodes). */
+int         la_gpu_mark(la_gpu_ctx *ctx);
+int         la_gpu_wait_mark(la_gpu_ctx *ctx);
+
 /* Stream-ordered timer (HIP events on the context's stream). */
 int         la_gpu_timer_start(la_gpu_ctx *ctx);
 int         la_gpu_timer_stop(la_gpu_ctx *ctx, float *elapsed_ms);	/* synchronises */

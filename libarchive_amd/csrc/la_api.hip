@@ -21,6 +21,7 @@ struct la_gpu_ctx {
 	hipStream_t own_stream;
 	hipStream_t stream;
 	hipEvent_t ev0, ev1;
+	hipEvent_t mark;
 	void *ws;
 	uint64_t ws_bytes;
 	/* second stream + events: block checksums / parse of later slices run beside the
@@ -90,7 +91,8 @@ int la_gpu_open(int device, la_gpu_ctx **out)
 	c->device = device;
 	if (hipSetDevice(device) != hipSuccess ||
 	    hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
-	    hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+	    hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+	    hipEventCreateWithFlags(&c->mark, hipEventDisableTiming) != hipSuccess) {
 		delete c;
 		return LA_ERR_NO_DEVICE;
 	}
@@ -115,6 +117,7 @@ void la_gpu_close(la_gpu_ctx *c)
 	if (c->ws) (void)hipFree(c->ws);
 	(void)hipEventDestroy(c->ev0);
 	(void)hipEventDestroy(c->ev1);
+	(void)hipEventDestroy(c->mark);
 	for (int i = 0; i < LA_PROF_MAX_RANGES; i++) {
 		(void)hipEventDestroy(c->prof_a[i]);
 		(void)hipEventDestroy(c->prof_b[i]);
@@ -193,6 +196,19 @@ int la_gpu_memcpy_d2h(la_gpu_ctx *c, void *h, const void *d, uint64_t bytes)
 {
 	if (!c) return LA_ERR_ARG;
 	if (bytes) HIPCHK(c, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream));
+	return LA_OK;
+}
+
+int la_gpu_mark(la_gpu_ctx *c)
+{
+	if (!c) return LA_ERR_ARG;
+	HIPCHK(c, hipEventRecord(c->mark, c->stream));
+	return LA_OK;
+}
+int la_gpu_wait_mark(la_gpu_ctx *c)
+{
+	if (!c) return LA_ERR_ARG;
+	HIPCHK(c, hipEventSynchronize(c->mark));
 	return LA_OK;
 }
 

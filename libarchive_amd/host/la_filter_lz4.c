@@ -30,19 +30,35 @@
 #include <errno.h>
 #include <stdio.h>
 
-struct lz4_private {
-	la_gpu_ctx *gpu;
+/* one window in flight: its buffers, its index, what the device said about it */
+struct lz4_slot {
 	/* compressed window (pinned host memory) */
 	uint8_t *stage;
 	size_t stage_cap, stage_len;
-	size_t batch_bytes;
-	int upstream_eof;
 	/* device buffers, grown on demand */
 	void *d_src, *d_dst, *d_tabs;
 	size_t d_src_cap, d_dst_cap, d_tabs_cap;
 	/* decoded slab handed to the read core (pinned host memory) */
 	uint8_t *slab;
 	size_t slab_cap;
+	la_batch_summary *h_sum;	/* pinned: the summary lands here asynchronously */
+	la_lz4_index idx;
+	int have_idx;		/* idx is valid (and owns memory) */
+	int launched;		/* device work for idx is queued */
+	size_t o_outlen, o_dstoff, o_bst, o_fst;	/* layout of d_tabs */
+};
+
+struct lz4_private {
+	la_gpu_ctx *gpu;
+	/* Two windows: while the caller consumes the slab of one (and while that slab is still
+	 * on its way over PCIe), the next window is gathered from upstream, indexed and queued
+	 * on the device.  Host copying, H2D, kernels and D2H of neighbouring windows overlap;
+	 * the order in which bytes and errors come out of read() does not change. */
+	struct lz4_slot slot[2];
+	int cur;
+	size_t batch_bytes;
+	int upstream_eof;
+	int upstream_fatal;	/* upstream failed while the NEXT window was gathered: reported after this one */
 	/* host copies of per-unit results (only fetched when a batch has an event) */
 	uint32_t *h_u32;
 	size_t h_u32_cap;
@@ -156,69 +172,143 @@ static int grow_dev(struct lz4_private *st, void **p, size_t *cap, size_t need)
 
 #define ALIGN256(x) (((x) + 255) & ~(size_t)255)
 
-/*
- * One batch.  Returns bytes delivered into st->slab (>= 0) or ARCHIVE_FATAL;
- * sets st->eof / st->pending_fatal for what follows those bytes.
- */
-static ssize_t lz4_run_batch(struct archive_read_filter *self, struct lz4_private *st,
-    const la_lz4_index *x)
+/* what the index alone says about the end of the stream (no device verdict involved) */
+static void lz4_apply_end_kind(struct lz4_private *st, int end_kind)
 {
+	switch (end_kind) {
+	case LA_END_TRUNCATED:
+	case LA_END_MALFORMED:
+	case LA_END_MALFORMED_SKIP:
+		st->pending_fatal = 1;
+		snprintf(st->pending_msg, sizeof(st->pending_msg), "%s", la_end_message(end_kind, 0));
+		break;
+	case LA_END_EOF:
+	case LA_END_EMPTY_FRAME:
+		st->eof = 1;
+		break;
+	default:	/* LA_END_NEED_MORE: the stream goes on in the next window */
+		break;
+	}
+}
+
+/*
+ * Gather one window into sl->stage (which may already hold the carried-over tail of the
+ * previous window) and index it.  0 = sl->idx is valid, ARCHIVE_FATAL on error.
+ */
+static int lz4_gather_and_index(struct archive_read_filter *self, struct lz4_private *st, struct lz4_slot *sl)
+{
+	for (;;) {
+		/* 1. gather compressed bytes until the window is full or upstream ends */
+		while (!st->upstream_eof && sl->stage_len < st->batch_bytes) {
+			ssize_t avail;
+			const void *up = __archive_read_filter_ahead(self->upstream, 1, &avail);
+			if (up == NULL) {
+				if (avail < 0)
+					return ARCHIVE_FATAL;	/* upstream already set the error */
+				st->upstream_eof = 1;
+				break;
+			}
+			size_t n = (size_t)avail;
+			if (n > st->batch_bytes - sl->stage_len)
+				n = st->batch_bytes - sl->stage_len;
+			if (grow_pinned(st, &sl->stage, &sl->stage_cap, sl->stage_len + n, sl->stage_len) < 0)
+				return gpu_fail(self, st, "pinned staging allocation");
+			memcpy(sl->stage + sl->stage_len, up, n);
+			sl->stage_len += n;
+			__archive_read_filter_consume(self->upstream, (int64_t)n);
+		}
+
+		/* 2. frame / block headers (host pointer chase, no payload byte touched) */
+		if (la_lz4_index_build(sl->stage, sl->stage_len, st->upstream_eof, &sl->idx) != 0) {
+			archive_set_error(&self->archive->archive, ENOMEM, "Can't allocate data for lz4 decompression");
+			return ARCHIVE_FATAL;
+		}
+		if (sl->idx.end_kind == LA_END_NEED_MORE && sl->idx.n_blocks == 0 && sl->idx.n_frames == 0 &&
+		    sl->idx.consumed == 0) {
+			/* a single frame larger than the window: widen the window and gather more */
+			la_lz4_index_free(&sl->idx);
+			st->batch_bytes *= 2;
+			continue;
+		}
+		sl->have_idx = 1;
+		return 0;
+	}
+}
+
+/* Queue the device work of sl->idx: H2D, decode, summary D2H.  Nothing is waited for. */
+static int lz4_launch(struct archive_read_filter *self, struct lz4_private *st, struct lz4_slot *sl)
+{
+	const la_lz4_index *x = &sl->idx;
 	const uint32_t nb = x->n_blocks, nf = x->n_frames;
 	const size_t src_len = (size_t)x->consumed;
 
-	if (nb == 0 && nf == 0) {
-		/* only skippable frames / trailing bytes in this window: nothing for the device */
-		switch (x->end_kind) {
-		case LA_END_TRUNCATED: case LA_END_MALFORMED: case LA_END_MALFORMED_SKIP:
-			st->pending_fatal = 1;
-			snprintf(st->pending_msg, sizeof(st->pending_msg), "%s", la_end_message(x->end_kind, 0));
-			break;
-		case LA_END_EOF: case LA_END_EMPTY_FRAME:
-			st->eof = 1;
-			break;
-		default:
-			break;
-		}
-		return 0;
-	}
+	sl->launched = 0;
+	if (nb == 0 && nf == 0)
+		return 0;	/* only skippable frames / trailing bytes in this window: nothing for the device */
 
 	/* layout of the table buffer on the device */
 	size_t o = 0;
 	const size_t o_blocks = o; o += ALIGN256((size_t)nb * sizeof(la_lz4_block));
 	const size_t o_frames = o; o += ALIGN256((size_t)nf * sizeof(la_lz4_frame));
-	const size_t o_outlen = o; o += ALIGN256((size_t)nb * 4);
-	const size_t o_dstoff = o; o += ALIGN256(((size_t)nb + 1) * 8);
-	const size_t o_bst = o; o += ALIGN256((size_t)nb * 4);
-	const size_t o_fst = o; o += ALIGN256((size_t)nf * 4);
+	sl->o_outlen = o; o += ALIGN256((size_t)nb * 4);
+	sl->o_dstoff = o; o += ALIGN256(((size_t)nb + 1) * 8);
+	sl->o_bst = o; o += ALIGN256((size_t)nb * 4);
+	sl->o_fst = o; o += ALIGN256((size_t)nf * 4);
 	const size_t o_sum = o; o += 256;
-	if (grow_dev(st, &st->d_src, &st->d_src_cap, src_len + 64) < 0 ||
-	    grow_dev(st, &st->d_dst, &st->d_dst_cap, (size_t)x->max_out + 64) < 0 ||
-	    grow_dev(st, &st->d_tabs, &st->d_tabs_cap, o) < 0)
+	if (grow_dev(st, &sl->d_src, &sl->d_src_cap, src_len + 64) < 0 ||
+	    grow_dev(st, &sl->d_dst, &sl->d_dst_cap, (size_t)x->max_out + 64) < 0 ||
+	    grow_dev(st, &sl->d_tabs, &sl->d_tabs_cap, o) < 0)
 		return gpu_fail(self, st, "device allocation");
-	uint8_t *T = st->d_tabs;
+	if (sl->h_sum == NULL) {
+		void *hp = NULL;
+		if (la_gpu_malloc_host(st->gpu, &hp, 256) != LA_OK)
+			return gpu_fail(self, st, "pinned summary allocation");
+		sl->h_sum = hp;
+	}
+	uint8_t *T = sl->d_tabs;
 
-	if (la_gpu_memcpy_h2d(st->gpu, st->d_src, st->stage, src_len) != LA_OK ||
+	if (la_gpu_memcpy_h2d(st->gpu, sl->d_src, sl->stage, src_len) != LA_OK ||
 	    la_gpu_memcpy_h2d(st->gpu, T + o_blocks, x->blocks, (size_t)nb * sizeof(la_lz4_block)) != LA_OK ||
 	    la_gpu_memcpy_h2d(st->gpu, T + o_frames, x->frames, (size_t)nf * sizeof(la_lz4_frame)) != LA_OK)
 		return gpu_fail(self, st, "host to device copy");
 
 	la_lz4_batch bt;
 	memset(&bt, 0, sizeof(bt));
-	bt.d_src = st->d_src; bt.src_bytes = src_len;
+	bt.d_src = sl->d_src; bt.src_bytes = src_len;
 	bt.d_blocks = (const la_lz4_block *)(T + o_blocks); bt.n_blocks = nb;
 	bt.d_frames = nf ? (const la_lz4_frame *)(T + o_frames) : NULL; bt.n_frames = nf;
-	bt.d_dst = st->d_dst; bt.dst_cap = x->max_out;
-	bt.d_out_len = (uint32_t *)(T + o_outlen);
-	bt.d_dst_off = (uint64_t *)(T + o_dstoff);
-	bt.d_block_status = (uint32_t *)(T + o_bst);
-	bt.d_frame_status = (uint32_t *)(T + o_fst);
+	bt.d_dst = sl->d_dst; bt.dst_cap = x->max_out;
+	bt.d_out_len = (uint32_t *)(T + sl->o_outlen);
+	bt.d_dst_off = (uint64_t *)(T + sl->o_dstoff);
+	bt.d_block_status = (uint32_t *)(T + sl->o_bst);
+	bt.d_frame_status = (uint32_t *)(T + sl->o_fst);
 	bt.d_summary = (la_batch_summary *)(T + o_sum);
 	if (la_gpu_lz4_decode(st->gpu, &bt) != LA_OK)
 		return gpu_fail(self, st, "la_gpu_lz4_decode");
-
-	la_batch_summary sm;
-	if (la_gpu_memcpy_d2h(st->gpu, &sm, T + o_sum, sizeof(sm)) != LA_OK || la_gpu_sync(st->gpu) != LA_OK)
+	if (la_gpu_memcpy_d2h(st->gpu, sl->h_sum, T + o_sum, sizeof(*sl->h_sum)) != LA_OK)
 		return gpu_fail(self, st, "summary copy");
+	sl->launched = 1;
+	return 0;
+}
+
+/*
+ * Wait for the window's verdict, settle what follows its bytes (st->eof / st->pending_fatal)
+ * and QUEUE the copy of the bytes to deliver into sl->slab (the caller waits for it with
+ * la_gpu_sync).  Returns bytes that will be delivered (>= 0) or ARCHIVE_FATAL.
+ */
+static ssize_t lz4_resolve(struct archive_read_filter *self, struct lz4_private *st, struct lz4_slot *sl)
+{
+	const la_lz4_index *x = &sl->idx;
+	const uint32_t nb = x->n_blocks, nf = x->n_frames;
+
+	if (!sl->launched) {
+		lz4_apply_end_kind(st, x->end_kind);
+		return 0;
+	}
+	if (la_gpu_sync(st->gpu) != LA_OK)
+		return gpu_fail(self, st, "summary copy");
+	const la_batch_summary sm = *sl->h_sum;
+	uint8_t *T = sl->d_tabs;
 
 	uint64_t delivered = sm.total_out;
 	uint32_t st_code = LA_ST_OK;
@@ -239,10 +329,10 @@ static ssize_t lz4_run_batch(struct archive_read_filter *self, struct lz4_privat
 		}
 		uint32_t *h_len = st->h_u32, *h_bst = h_len + nb, *h_fst = h_bst + nb;
 		uint64_t *h_off = (uint64_t *)(h_fst + nf + ((nb * 2 + nf) & 1));
-		if (la_gpu_memcpy_d2h(st->gpu, h_len, T + o_outlen, (size_t)nb * 4) != LA_OK ||
-		    la_gpu_memcpy_d2h(st->gpu, h_bst, T + o_bst, (size_t)nb * 4) != LA_OK ||
-		    la_gpu_memcpy_d2h(st->gpu, h_fst, T + o_fst, (size_t)nf * 4) != LA_OK ||
-		    la_gpu_memcpy_d2h(st->gpu, h_off, T + o_dstoff, ((size_t)nb + 1) * 8) != LA_OK ||
+		if (la_gpu_memcpy_d2h(st->gpu, h_len, T + sl->o_outlen, (size_t)nb * 4) != LA_OK ||
+		    la_gpu_memcpy_d2h(st->gpu, h_bst, T + sl->o_bst, (size_t)nb * 4) != LA_OK ||
+		    la_gpu_memcpy_d2h(st->gpu, h_fst, T + sl->o_fst, (size_t)nf * 4) != LA_OK ||
+		    la_gpu_memcpy_d2h(st->gpu, h_off, T + sl->o_dstoff, ((size_t)nb + 1) * 8) != LA_OK ||
 		    la_gpu_sync(st->gpu) != LA_OK)
 			return gpu_fail(self, st, "status copy");
 		int found = 0;
@@ -274,30 +364,39 @@ static ssize_t lz4_run_batch(struct archive_read_filter *self, struct lz4_privat
 	} else if (silent_end) {
 		st->eof = 1;
 	} else {
-		switch (x->end_kind) {
-		case LA_END_TRUNCATED:
-		case LA_END_MALFORMED:
-		case LA_END_MALFORMED_SKIP:
-			st->pending_fatal = 1;
-			snprintf(st->pending_msg, sizeof(st->pending_msg), "%s", la_end_message(x->end_kind, 0));
-			break;
-		case LA_END_EOF:
-		case LA_END_EMPTY_FRAME:
-			st->eof = 1;
-			break;
-		default:	/* LA_END_NEED_MORE: the stream goes on in the next batch */
-			break;
-		}
+		lz4_apply_end_kind(st, x->end_kind);
 	}
 
 	if (delivered) {
-		if (grow_pinned(st, &st->slab, &st->slab_cap, (size_t)delivered, 0) < 0)
+		if (grow_pinned(st, &sl->slab, &sl->slab_cap, (size_t)delivered, 0) < 0)
 			return gpu_fail(self, st, "pinned slab allocation");
-		if (la_gpu_memcpy_d2h(st->gpu, st->slab, st->d_dst, (size_t)delivered) != LA_OK ||
-		    la_gpu_sync(st->gpu) != LA_OK)
+		if (la_gpu_memcpy_d2h(st->gpu, sl->slab, sl->d_dst, (size_t)delivered) != LA_OK ||
+		    la_gpu_mark(st->gpu) != LA_OK)
 			return gpu_fail(self, st, "device to host copy");
 	}
 	return (ssize_t)delivered;
+}
+
+/* window `from` has been indexed: its unconsumed tail (an incomplete frame) opens window `to` */
+static int lz4_carry_tail(struct archive_read_filter *self, struct lz4_private *st, struct lz4_slot *from,
+    struct lz4_slot *to)
+{
+	const size_t used = (size_t)from->idx.consumed;
+	const size_t tail = used < from->stage_len ? from->stage_len - used : 0;
+	if (grow_pinned(st, &to->stage, &to->stage_cap, tail ? tail : 1, 0) < 0)
+		return gpu_fail(self, st, "pinned staging allocation");
+	if (tail)
+		memcpy(to->stage, from->stage + used, tail);
+	to->stage_len = tail;
+	return 0;
+}
+
+static void lz4_slot_done(struct lz4_slot *sl)
+{
+	if (sl->have_idx)
+		la_lz4_index_free(&sl->idx);
+	sl->have_idx = 0;
+	sl->launched = 0;
 }
 
 static ssize_t lz4_filter_read(struct archive_read_filter *self, const void **p)
@@ -312,55 +411,50 @@ static ssize_t lz4_filter_read(struct archive_read_filter *self, const void **p)
 		}
 		if (st->eof)
 			return 0;
+		if (st->upstream_fatal)
+			return ARCHIVE_FATAL;	/* upstream set the error while the window was gathered */
 
-		/* 1. gather compressed bytes until the window is full or upstream ends */
-		while (!st->upstream_eof && st->stage_len < st->batch_bytes) {
-			ssize_t avail;
-			const void *up = __archive_read_filter_ahead(self->upstream, 1, &avail);
-			if (up == NULL) {
-				if (avail < 0)
-					return ARCHIVE_FATAL;	/* upstream already set the error */
-				st->upstream_eof = 1;
-				break;
-			}
-			size_t n = (size_t)avail;
-			if (n > st->batch_bytes - st->stage_len)
-				n = st->batch_bytes - st->stage_len;
-			if (grow_pinned(st, &st->stage, &st->stage_cap, st->stage_len + n, st->stage_len) < 0)
-				return gpu_fail(self, st, "pinned staging allocation");
-			memcpy(st->stage + st->stage_len, up, n);
-			st->stage_len += n;
-			__archive_read_filter_consume(self->upstream, (int64_t)n);
+		struct lz4_slot *sl = &st->slot[st->cur], *nx = &st->slot[st->cur ^ 1];
+		if (!sl->have_idx) {
+			/* nothing in flight (first call, or the previous window delivered nothing) */
+			int r = lz4_gather_and_index(self, st, sl);
+			if (r != 0)
+				return r;
+			if ((r = lz4_launch(self, st, sl)) != 0)
+				return r;
+			if ((r = lz4_carry_tail(self, st, sl, nx)) != 0)
+				return r;
 		}
 
-		/* 2. frame / block headers (host pointer chase, no payload byte touched) */
-		la_lz4_index idx;
-		if (la_lz4_index_build(st->stage, st->stage_len, st->upstream_eof, &idx) != 0) {
-			archive_set_error(&self->archive->archive, ENOMEM, "Can't allocate data for lz4 decompression");
-			return ARCHIVE_FATAL;
-		}
-		if (idx.end_kind == LA_END_NEED_MORE && idx.n_blocks == 0 && idx.n_frames == 0 && idx.consumed == 0) {
-			/* a single frame larger than the window: widen the window and gather more */
-			la_lz4_index_free(&idx);
-			st->batch_bytes *= 2;
-			continue;
-		}
-
-		/* 3. + 4. device batch and stream-order outcome */
-		ssize_t n = lz4_run_batch(self, st, &idx);
-		size_t used = (size_t)idx.consumed;
-		la_lz4_index_free(&idx);
+		/* 3. the window's verdict; its bytes start moving to the host */
+		ssize_t n = lz4_resolve(self, st, sl);
 		if (n < 0)
 			return n;
-		/* keep the unconsumed tail (an incomplete frame) for the next batch */
-		if (used < st->stage_len)
-			memmove(st->stage, st->stage + used, st->stage_len - used);
-		st->stage_len -= used;
+
+		/* 4. while they move (and while the caller then consumes them): the next window */
+		if (!st->pending_fatal && !st->eof && sl->idx.end_kind == LA_END_NEED_MORE) {
+			int r = lz4_gather_and_index(self, st, nx);
+			if (r != 0) {
+				if (n == 0)
+					return r;
+				st->upstream_fatal = 1;	/* after this window's bytes */
+			} else {
+				if ((r = lz4_launch(self, st, nx)) != 0)
+					return r;
+				if ((r = lz4_carry_tail(self, st, nx, sl)) != 0)	/* (sl's stage is free: its H2D is done) */
+					return r;
+			}
+		}
+		/* only the slab copy is waited for: the next window keeps running on the device */
+		if (n > 0 && la_gpu_wait_mark(st->gpu) != LA_OK)
+			return gpu_fail(self, st, "device to host copy");
+		lz4_slot_done(sl);
+		st->cur ^= 1;
 		if (n > 0) {
-			*p = st->slab;
+			*p = sl->slab;
 			return n;
 		}
-		/* nothing to deliver from this batch: report what follows, or go on */
+		/* nothing to deliver from this window: report what follows, or go on */
 	}
 }
 
@@ -371,11 +465,16 @@ static int lz4_filter_close(struct archive_read_filter *self)
 		return ARCHIVE_OK;
 	if (st->gpu) {
 		la_gpu_sync(st->gpu);
-		if (st->stage) la_gpu_free_host(st->gpu, st->stage);
-		if (st->slab) la_gpu_free_host(st->gpu, st->slab);
-		if (st->d_src) la_gpu_free(st->gpu, st->d_src);
-		if (st->d_dst) la_gpu_free(st->gpu, st->d_dst);
-		if (st->d_tabs) la_gpu_free(st->gpu, st->d_tabs);
+		for (int i = 0; i < 2; i++) {
+			struct lz4_slot *sl = &st->slot[i];
+			lz4_slot_done(sl);
+			if (sl->stage) la_gpu_free_host(st->gpu, sl->stage);
+			if (sl->slab) la_gpu_free_host(st->gpu, sl->slab);
+			if (sl->h_sum) la_gpu_free_host(st->gpu, sl->h_sum);
+			if (sl->d_src) la_gpu_free(st->gpu, sl->d_src);
+			if (sl->d_dst) la_gpu_free(st->gpu, sl->d_dst);
+			if (sl->d_tabs) la_gpu_free(st->gpu, sl->d_tabs);
+		}
 		la_gpu_close(st->gpu);
 	}
 	free(st->h_u32);
