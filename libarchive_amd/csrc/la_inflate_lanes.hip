@@ -30,6 +30,9 @@
 #define LL_BITS 7
 #endif
 #define DT_BITS 6
+#ifndef IL_LIT_ROUNDS
+#define IL_LIT_ROUNDS 2
+#endif
 #ifndef IL_LIT_BURST
 #define IL_LIT_BURST 3	/* (3 x 15 bits fit the one refill of a burst) */
 #endif
@@ -518,21 +521,26 @@ __global__ __launch_bounds__(IL_THREADS) void inflate_lanes_kernel(const uint8_t
 				 * three literal/length codes are at most 45 bits, so the burst itself needs no
 				 * per-symbol refill test -- with 64 lanes that test fires for some lane in
 				 * every iteration and the whole wave pays for the refill code each time */
-				lb_refill(B);
+#pragma unroll	/* IL_LIT_ROUNDS bursts back to back before the match path: it is paid per outer iteration */
+				for (int rnd = 0; rnd < IL_LIT_ROUNDS; rnd++) {
+					lb_refill(B);
 #pragma unroll	/* (no loop around the burst: a loop head makes the compiler wait for the prefetch there) */
-				for (int burst = 0; burst < IL_LIT_BURST; burst++) {
-					sym = il_decode<LL_BITS, true>(B, CL, sorted_ll, T, tid, &used);
-					IL_CHECK_TRUNC();
-					if (sym < 0) { status = LA_ST_GZ_DATA; goto done; }
+					for (int burst = 0; burst < IL_LIT_BURST; burst++) {
+						sym = il_decode<LL_BITS, true>(B, CL, sorted_ll, T, tid, &used);
+						IL_CHECK_TRUNC();
+						if (sym < 0) { status = LA_ST_GZ_DATA; goto done; }
+						if (sym >= 256)
+							break;
+						if (op >= cap) { status = LA_ST_GZ_OUT_FULL; goto done; }
+						if (EMIT) {
+							IL_PUT_LIT((uint32_t)sym);
+							op++;
+						} else {
+							d[op++] = (uint8_t)sym;
+						}
+					}
 					if (sym >= 256)
 						break;
-					if (op >= cap) { status = LA_ST_GZ_OUT_FULL; goto done; }
-					if (EMIT) {
-						IL_PUT_LIT((uint32_t)sym);
-						op++;
-					} else {
-						d[op++] = (uint8_t)sym;
-					}
 				}
 				if (sym < 256)
 					continue;	/* the burst ended on a literal: next burst */
