@@ -52,7 +52,9 @@
 #ifndef PS_THREADS
 #define PS_THREADS 64u		/* waves of a workgroup share nothing: the size only sets the LDS granule */
 #endif
+#ifndef PS_STAGE
 #define PS_STAGE   16u		/* staged table entries per lane (two groups of eight) */
+#endif
 #define PS_WAVES   (PS_THREADS / 64u)
 #define PS_RINGW   (2u * PS_CH / 4u)	/* ring = two chunks, in dwords (power of two) */
 #define PS_PIECES  (PS_CH / 16u)	/* 16-byte pieces per chunk = load instructions per round */
