@@ -8,8 +8,17 @@ import libarchive_amd as la
 ARCHIVE_EOF, ARCHIVE_OK, ARCHIVE_FATAL = 1, 0, -30
 
 
+_OVERRIDE = None   # a ctypes CDLL to use instead of the product's libla_host.so (tests/mock_gpu)
+
+
+def use_library(cdll):
+    """Route this harness to another build of the host library (None = the product's)."""
+    global _OVERRIDE
+    _OVERRIDE = cdll
+
+
 def _lib():
-    lib = la.host_lib()
+    lib = _OVERRIDE if _OVERRIDE is not None else la.host_lib()
     if getattr(lib, "_la_api_ready", False):
         return lib
     lib.archive_read_new.restype = C.c_void_p

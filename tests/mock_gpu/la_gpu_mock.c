@@ -1,0 +1,167 @@
+/*
+ * la_gpu_mock.c -- TEST INFRASTRUCTURE ONLY.  A CPU stand-in for the device C ABI of
+ * include/la_gpu.h, built from the oracle (oracle/la_oracle.h), so that the plain-C host side
+ * (read core, both filters, walkers, la_cat) can be exercised end to end by the `-m "not gpu"`
+ * suite on a machine without a GPU: filter state machines, window pipelining, stream-order
+ * error resolution, carry buffers.  It is never linked into the product: tests/mock_gpu/Makefile
+ * builds a separate libla_host_mock.so against it, and nothing under libarchive_amd/ refers to
+ * it.  "Device" memory is host memory, copies are memcpy, everything is synchronous.
+ */
+#include "../../include/la_gpu.h"
+#include "../../oracle/la_oracle.h"
+#include <stdlib.h>
+#include <string.h>
+
+struct la_gpu_ctx { char err[64]; };
+
+int la_gpu_abi_version(void) { return 1; }
+int la_gpu_device_count(void) { return 1; }
+int la_gpu_open(int device, la_gpu_ctx **out)
+{
+	(void)device;
+	*out = calloc(1, sizeof(**out));
+	return *out ? LA_OK : LA_ERR_NOMEM;
+}
+void la_gpu_close(la_gpu_ctx *c) { free(c); }
+int la_gpu_set_stream(la_gpu_ctx *c, void *s) { (void)c; (void)s; return LA_OK; }
+int la_gpu_sync(la_gpu_ctx *c) { (void)c; return LA_OK; }
+int la_gpu_mark(la_gpu_ctx *c) { (void)c; return LA_OK; }
+int la_gpu_wait_mark(la_gpu_ctx *c) { (void)c; return LA_OK; }
+const char *la_gpu_last_error(const la_gpu_ctx *c) { return c ? c->err : "no context"; }
+int la_gpu_reserve(la_gpu_ctx *c, uint64_t b) { (void)c; (void)b; return LA_OK; }
+int la_gpu_malloc(la_gpu_ctx *c, void **p, uint64_t n) { (void)c; *p = malloc(n ? n : 1); return *p ? LA_OK : LA_ERR_NOMEM; }
+int la_gpu_free(la_gpu_ctx *c, void *p) { (void)c; free(p); return LA_OK; }
+int la_gpu_malloc_host(la_gpu_ctx *c, void **p, uint64_t n) { return la_gpu_malloc(c, p, n); }
+int la_gpu_free_host(la_gpu_ctx *c, void *p) { return la_gpu_free(c, p); }
+int la_gpu_memcpy_h2d(la_gpu_ctx *c, void *d, const void *h, uint64_t n) { (void)c; if (n) memcpy(d, h, n); return LA_OK; }
+int la_gpu_memcpy_d2h(la_gpu_ctx *c, void *h, const void *d, uint64_t n) { (void)c; if (n) memcpy(h, d, n); return LA_OK; }
+
+static void summary_init(la_batch_summary *sm)
+{
+	memset(sm, 0, sizeof(*sm));
+	sm->first_bad_unit = sm->first_bad_frame = sm->first_zero_unit = 0xFFFFFFFFu;
+}
+
+/* what the device kernels produce for a table of lz4 blocks / frames (tests/emu.py is the same in Python) */
+int la_gpu_lz4_decode(la_gpu_ctx *c, const la_lz4_batch *bt)
+{
+	(void)c;
+	const int verify = !(bt->options & LA_LZ4_OPT_NO_VERIFY);
+	uint64_t off = 0;
+	uint32_t prev_len = 0;
+	uint8_t *dict = malloc(65536);
+	if (!dict) return LA_ERR_NOMEM;
+	for (uint32_t i = 0; i < bt->n_blocks; i++) {
+		const la_lz4_block *b = &bt->d_blocks[i];
+		const uint8_t *pay = bt->d_src + b->src_off;
+		uint32_t st = LA_ST_OK, olen = 0;
+		bt->d_dst_off[i] = off;
+		if (verify && (b->flags & LA_LZ4B_CHECKSUM) && orc_xxh32(pay, b->src_len, 0) != b->block_sum)
+			st = LA_ST_LZ4_BAD_BLOCK_SUM;
+		else if (b->flags & LA_LZ4B_STORED) {
+			olen = b->src_len;
+			if (off + olen <= bt->dst_cap)
+				memcpy(bt->d_dst + off, pay, olen);
+			else { st = LA_ST_LZ4_DECODE; olen = 0; }
+		} else {
+			const uint8_t *dp = NULL;
+			int dl = 0;
+			if (b->flags & LA_LZ4B_DEPENDENT) {
+				/* lz4.c:563-577: the previous block (at most 64 KiB), zero padded in front */
+				const uint32_t keep = (b->flags & LA_LZ4B_FIRST) ? 0 : (prev_len < 65536u ? prev_len : 65536u);
+				memset(dict, 0, 65536 - keep);
+				if (keep)
+					memcpy(dict + 65536 - keep, bt->d_dst + off - keep, keep);
+				dp = dict; dl = 65536;
+			}
+			uint64_t room = bt->dst_cap > off ? bt->dst_cap - off : 0;
+			int cap = (int)(b->dst_cap < room ? b->dst_cap : room);
+			int r = orc_lz4_block_decode(pay, (int)b->src_len, bt->d_dst + off, cap, dp, dl);
+			if (r < 0) st = LA_ST_LZ4_DECODE; else olen = (uint32_t)r;
+		}
+		bt->d_out_len[i] = olen;
+		bt->d_block_status[i] = st;
+		prev_len = olen;
+		off += olen;
+	}
+	bt->d_dst_off[bt->n_blocks] = off;
+	free(dict);
+	for (uint32_t k = 0; k < bt->n_frames; k++) {
+		const la_lz4_frame *f = &bt->d_frames[k];
+		uint32_t st = LA_ST_OK;
+		if (verify && (f->flags & LA_LZ4F_HEADER_SUM)) {
+			const uint8_t *d = bt->d_src + f->desc_off;
+			if (((orc_xxh32(d, f->desc_len - 1, 0) >> 8) & 0xff) != d[f->desc_len - 1])
+				st = LA_ST_LZ4_BAD_HEADER_SUM;
+		}
+		if (verify && st == LA_ST_OK && (f->flags & LA_LZ4F_CONTENT_SUM)) {
+			const uint64_t a = bt->d_dst_off[f->first_block], e = bt->d_dst_off[f->first_block + f->n_blocks];
+			if (orc_xxh32(bt->d_dst + a, (size_t)(uint32_t)(e - a), 0) != f->content_sum)
+				st = LA_ST_LZ4_BAD_CONTENT_SUM;
+		}
+		bt->d_frame_status[k] = st;
+	}
+	if (bt->d_summary) {
+		la_batch_summary *sm = bt->d_summary;
+		summary_init(sm);
+		for (uint32_t i = 0; i < bt->n_blocks; i++) {
+			if (bt->d_block_status[i] != LA_ST_OK) {
+				sm->n_bad_units++;
+				if (sm->first_bad_unit == 0xFFFFFFFFu) sm->first_bad_unit = i;
+			} else if (bt->d_out_len[i] == 0 && sm->first_zero_unit == 0xFFFFFFFFu)
+				sm->first_zero_unit = i;
+		}
+		for (uint32_t k = 0; k < bt->n_frames; k++)
+			if (bt->d_frame_status[k] != LA_ST_OK) {
+				sm->n_bad_frames++;
+				if (sm->first_bad_frame == 0xFFFFFFFFu) sm->first_bad_frame = k;
+			}
+		sm->total_out = off;
+	}
+	return LA_OK;
+}
+
+int la_gpu_gzip_decode(la_gpu_ctx *c, const la_gz_batch *bt)
+{
+	(void)c;
+	const int verify = !(bt->options & LA_GZ_OPT_NO_VERIFY);
+	la_batch_summary sm;
+	summary_init(&sm);
+	for (uint32_t i = 0; i < bt->n_members; i++) {
+		const la_gz_member *m = &bt->d_members[i];
+		la_gz_result *r = &bt->d_results[i];
+		uint64_t room = m->src_off < bt->src_bytes ? bt->src_bytes - m->src_off : 0;
+		size_t slen = m->src_len < room ? m->src_len : (size_t)room;
+		uint64_t cap = m->dst_cap;
+		if (m->dst_off + cap > bt->dst_cap)
+			cap = m->dst_off < bt->dst_cap ? bt->dst_cap - m->dst_off : 0;
+		size_t cons = 0, prod = 0;
+		int rc = orc_inflate_raw(bt->d_src + m->src_off, slen, bt->d_dst + m->dst_off, (size_t)cap, &cons, &prod);
+		r->status = rc == ORC_INF_OK ? LA_ST_OK : rc == ORC_INF_TRUNCATED ? LA_ST_GZ_TRUNCATED :
+		    rc == ORC_INF_DATA_ERROR ? LA_ST_GZ_DATA : LA_ST_GZ_OUT_FULL;
+		r->out_len = (uint32_t)prod;
+		r->consumed = (uint32_t)cons;
+		r->crc32 = 0;
+		if (r->status == LA_ST_OK) {
+			r->crc32 = orc_crc32(0, bt->d_dst + m->dst_off, prod);
+			const uint64_t tr = m->src_off + cons;
+			if (cons + 8 > m->src_len || tr + 8 > bt->src_bytes)
+				r->status = LA_ST_GZ_NO_TRAILER;
+			else if (verify) {
+				const uint8_t *t = bt->d_src + tr;
+				const uint32_t want_crc = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+				const uint32_t want_len = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+				if (want_crc != r->crc32) r->status = LA_ST_GZ_BAD_CRC;
+				else if (want_len != r->out_len) r->status = LA_ST_GZ_BAD_ISIZE;
+			}
+		}
+		sm.total_out += r->out_len;
+		if (r->status != LA_ST_OK) {
+			sm.n_bad_units++;
+			if (sm.first_bad_unit == 0xFFFFFFFFu) sm.first_bad_unit = i;
+		}
+	}
+	if (bt->d_summary)
+		*bt->d_summary = sm;
+	return LA_OK;
+}
