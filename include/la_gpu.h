@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LA_GPU_ABI_VERSION 1
+#define LA_GPU_ABI_VERSION 2
 
 typedef enum la_rc {
 	LA_OK            = 0,
@@ -136,6 +136,10 @@ typedef struct la_lz4_block {
 
 #define LA_LZ4F_CONTENT_SUM 1u	/* content_sum holds the LE32 after the EndMark (lz4.c:639-662) */
 #define LA_LZ4F_HEADER_SUM  2u	/* verify descriptor check byte (lz4.c:446-451) */
+#define LA_LZ4F_CONT        4u	/* the frame began in an earlier batch: no descriptor here, its content hash
+					 * continues from d_carry_in */
+#define LA_LZ4F_OPEN        8u	/* the frame goes on in the next batch: its content hash state goes to d_carry_out */
+#define LA_LZ4F_HASHED     16u	/* the frame carries a content checksum (set on every piece of such a frame) */
 
 typedef struct la_lz4_frame {
 	uint64_t desc_off;	/* offset of FLG inside d_src */
@@ -180,7 +184,13 @@ typedef struct la_lz4_batch {
 	la_batch_summary   *d_summary;		/* one record */
 	uint32_t            options;		/* LA_LZ4_OPT_* */
 	uint32_t            reserved;
+	/* XXH32 state of a content checksum that spans batches (one frame at most enters a batch
+	 * and one at most leaves it unfinished): LA_XXH_CARRY_BYTES each, may be NULL when no
+	 * frame has LA_LZ4F_CONT / LA_LZ4F_OPEN.  Must be two different buffers. */
+	const void         *d_carry_in;
+	void               *d_carry_out;
 } la_lz4_batch;
+#define LA_XXH_CARRY_BYTES 64u
 
 /* Workspace bytes la_gpu_lz4_decode() needs for this shape (for la_gpu_reserve). */
 uint64_t la_gpu_lz4_workspace_bytes(uint32_t n_blocks, uint64_t src_bytes);

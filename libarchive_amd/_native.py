@@ -30,7 +30,7 @@ assert LZ4_BLOCK_DTYPE.itemsize == 24 and LZ4_FRAME_DTYPE.itemsize == 32
 assert HASH_JOB_DTYPE.itemsize == 16 and SUMMARY_DTYPE.itemsize == 32
 
 LA_LZ4B_STORED, LA_LZ4B_CHECKSUM, LA_LZ4B_DEPENDENT, LA_LZ4B_FIRST = 1, 2, 4, 8
-LA_LZ4F_CONTENT_SUM, LA_LZ4F_HEADER_SUM = 1, 2
+LA_LZ4F_CONTENT_SUM, LA_LZ4F_HEADER_SUM, LA_LZ4F_CONT, LA_LZ4F_OPEN, LA_LZ4F_HASHED = 1, 2, 4, 8, 16
 LA_LZ4_OPT_GENERAL_ONLY, LA_LZ4_OPT_NO_VERIFY, LA_LZ4_OPT_PARSE_V1 = 1, 2, 4
 
 (LA_END_EOF, LA_END_TRUNCATED, LA_END_MALFORMED, LA_END_MALFORMED_SKIP, LA_END_EMPTY_FRAME,
@@ -51,6 +51,7 @@ class _Lz4BatchC(C.Structure):
         ("d_block_status", C.c_void_p), ("d_frame_status", C.c_void_p),
         ("d_summary", C.c_void_p),
         ("options", C.c_uint32), ("reserved", C.c_uint32),
+        ("d_carry_in", C.c_void_p), ("d_carry_out", C.c_void_p),   # content hash across batches (NULL here)
     ]
 
 

@@ -228,7 +228,8 @@ void la_launch_lz4_block_sums(hipStream_t s, const uint8_t *d_src, const la_lz4_
     uint32_t n, uint32_t *d_status);
 void la_launch_lz4_frame_sums(hipStream_t s, const uint8_t *d_src, const uint8_t *d_dst,
     const la_lz4_frame *d_frames, uint32_t n_frames, const uint64_t *d_dst_off,
-    uint64_t dst_cap, uint32_t *d_frame_status, uint32_t end_lo, uint32_t end_hi);
+    uint64_t dst_cap, uint32_t *d_frame_status, uint32_t end_lo, uint32_t end_hi,
+    const void *d_carry_in, void *d_carry_out);
 void la_launch_lz4_merge_status(hipStream_t s, const uint32_t *d_sum_status, uint32_t n, uint32_t *d_status);
 
 /* la_lz4.hip, la_lz4_fast.hip */

@@ -62,10 +62,103 @@ __global__ __launch_bounds__(256) void lz4_block_sums_kernel(const uint8_t *__re
 /* per frame: descriptor check byte (lz4.c:446-451) and content checksum over the
  * frame's decoded bytes (lz4.c:639-665).  Four lanes per frame (xxh32_quad): frames
  * are few and their chains long. */
+/* XXH32 state of a content checksum that spans batches (LA_XXH_CARRY_BYTES on the device):
+ * the streaming form of libarchive/xxhash.c:325-507 (XXH32_init / _update / _digest) */
+struct la_xxh_carry {
+	uint32_t v[4];
+	uint32_t memsize;	/* bytes waiting in mem for a full 16-byte stripe */
+	uint32_t total_lo, total_hi;
+	uint8_t mem[16];
+	uint32_t pad[5];
+};
+static_assert(sizeof(la_xxh_carry) == LA_XXH_CARRY_BYTES, "carry record size");
+
+/*
+ * One piece [p, p+n) of a hash that began in an earlier batch (cin != NULL) and/or goes on in
+ * the next one (cout != NULL).  Four lanes per hash as in xxh32_quad: lane j owns accumulator
+ * j.  Returns the digest when cout == NULL (valid in all four lanes).
+ */
+__device__ uint32_t xxh32_quad_stream(const la_xxh_carry *cin, la_xxh_carry *cout, const uint8_t *p, uint64_t n, int j)
+{
+	uint32_t v = (j == 0) ? XXH_P1 + XXH_P2 : (j == 1) ? XXH_P2 : (j == 2) ? 0u : 0u - XXH_P1;
+	uint32_t msz = 0;
+	uint64_t total = 0;
+	uint8_t mem[16];
+	for (int k = 0; k < 16; k++) mem[k] = 0;
+	if (cin) {
+		v = cin->v[j];
+		msz = cin->memsize;
+		total = ((uint64_t)cin->total_hi << 32) | cin->total_lo;
+		for (int k = 0; k < 16; k++) mem[k] = cin->mem[k];
+	}
+	total += n;
+	if (msz + n < 16) {
+		/* still no full stripe: the bytes join the waiting ones (xxhash.c:377-381) */
+		for (uint64_t k = 0; k < n; k++) mem[msz + k] = p[k];
+		msz += (uint32_t)n;
+		n = 0;
+	} else {
+		if (msz) {
+			/* complete the waiting stripe first (xxhash.c:383-401) */
+			const uint32_t need = 16 - msz;
+			for (uint32_t k = 0; k < need; k++) mem[msz + k] = p[k];
+			const uint32_t dw = (uint32_t)mem[4 * j] | ((uint32_t)mem[4 * j + 1] << 8) |
+			    ((uint32_t)mem[4 * j + 2] << 16) | ((uint32_t)mem[4 * j + 3] << 24);
+			v = xxh_round(v, dw);
+			p += need; n -= need; msz = 0;
+		}
+		const uint8_t *q = p + 4 * j;
+		uint64_t left = n;
+		while (left >= 512) {	/* 32 stripes of loads in flight per quad, as in xxh32_quad */
+			uint32_t x[32];
+#pragma unroll
+			for (int t = 0; t < 32; t++)
+				x[t] = ld_u32(q + 16 * t);
+#pragma unroll
+			for (int t = 0; t < 32; t++)
+				v = xxh_round(v, x[t]);
+			q += 512; left -= 512;
+		}
+		while (left >= 16) {
+			v = xxh_round(v, ld_u32(q));
+			q += 16; left -= 16;
+		}
+		const uint8_t *tailp = p + (n - left);
+		for (uint32_t k = 0; k < (uint32_t)left; k++) mem[k] = tailp[k];
+		msz = (uint32_t)left;
+	}
+	if (cout) {
+		cout->v[j] = v;
+		if (j == 0) {
+			cout->memsize = msz;
+			cout->total_lo = (uint32_t)total;
+			cout->total_hi = (uint32_t)(total >> 32);
+			for (int k = 0; k < 16; k++) cout->mem[k] = mem[k];
+		}
+		return 0;
+	}
+	/* digest (xxhash.c:447-507) */
+	uint32_t h;
+	const int rot = (j == 0) ? 1 : (j == 1) ? 7 : (j == 2) ? 12 : 18;
+	uint32_t t = rotl32(v, rot);
+	t += __shfl_xor(t, 1, 64);
+	t += __shfl_xor(t, 2, 64);
+	h = total >= 16 ? t : XXH_P5;
+	h += (uint32_t)total;
+	uint32_t k = 0;
+	for (; k + 4 <= msz; k += 4) {
+		const uint32_t dw = (uint32_t)mem[k] | ((uint32_t)mem[k + 1] << 8) | ((uint32_t)mem[k + 2] << 16) | ((uint32_t)mem[k + 3] << 24);
+		h = rotl32(h + dw * XXH_P3, 17) * XXH_P4;
+	}
+	for (; k < msz; k++)
+		h = rotl32(h + (uint32_t)mem[k] * XXH_P5, 11) * XXH_P1;
+	return xxh_avalanche(h);
+}
+
 __global__ __launch_bounds__(64) void lz4_frame_sums_kernel(const uint8_t *__restrict__ src,
     const uint8_t *__restrict__ dst, const la_lz4_frame *__restrict__ frames, uint32_t n,
     const uint64_t *__restrict__ dst_off, uint64_t dst_cap, uint32_t *__restrict__ fstatus,
-    uint32_t end_lo, uint32_t end_hi)
+    uint32_t end_lo, uint32_t end_hi, const la_xxh_carry *carry_in, la_xxh_carry *carry_out)
 {
 	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
 	uint32_t i = t >> 2;
@@ -84,7 +177,18 @@ __global__ __launch_bounds__(64) void lz4_frame_sums_kernel(const uint8_t *__res
 		if (((h >> 8) & 0xff) != src[f.desc_off + f.desc_len - 1])
 			st = LA_ST_LZ4_BAD_HEADER_SUM;
 	}
-	if (st == LA_ST_OK && (f.flags & LA_LZ4F_CONTENT_SUM)) {
+	if (st == LA_ST_OK && (f.flags & (LA_LZ4F_CONT | LA_LZ4F_OPEN))) {
+		/* a frame larger than one batch: its content hash comes in and / or goes out as state */
+		if ((f.flags & LA_LZ4F_HASHED) && carry_in && carry_out) {
+			uint64_t a = dst_off[f.first_block], e = dst_off[f.first_block + f.n_blocks];
+			if (e <= dst_cap) {
+				const uint32_t h = xxh32_quad_stream((f.flags & LA_LZ4F_CONT) ? carry_in : nullptr,
+				    (f.flags & LA_LZ4F_OPEN) ? carry_out : nullptr, dst + a, e - a, j);
+				if (!(f.flags & LA_LZ4F_OPEN) && (f.flags & LA_LZ4F_CONTENT_SUM) && h != f.content_sum)
+					st = LA_ST_LZ4_BAD_CONTENT_SUM;
+			}
+		}
+	} else if (st == LA_ST_OK && (f.flags & LA_LZ4F_CONTENT_SUM)) {
 		uint64_t a = dst_off[f.first_block], e = dst_off[f.first_block + f.n_blocks];
 		if (e <= dst_cap) {
 			/* xxhash.c:234: the length is an unsigned int there */
@@ -113,11 +217,12 @@ void la_launch_lz4_block_sums(hipStream_t s, const uint8_t *d_src, const la_lz4_
 
 void la_launch_lz4_frame_sums(hipStream_t s, const uint8_t *d_src, const uint8_t *d_dst,
     const la_lz4_frame *d_frames, uint32_t n_frames, const uint64_t *d_dst_off, uint64_t dst_cap,
-    uint32_t *d_frame_status, uint32_t end_lo, uint32_t end_hi)
+    uint32_t *d_frame_status, uint32_t end_lo, uint32_t end_hi, const void *d_carry_in, void *d_carry_out)
 {
 	if (n_frames == 0) return;
 	hipLaunchKernelGGL(lz4_frame_sums_kernel, dim3((n_frames + 15) / 16), dim3(64), 0, s,
-	    d_src, d_dst, d_frames, n_frames, d_dst_off, dst_cap, d_frame_status, end_lo, end_hi);
+	    d_src, d_dst, d_frames, n_frames, d_dst_off, dst_cap, d_frame_status, end_lo, end_hi,
+	    (const la_xxh_carry *)d_carry_in, (la_xxh_carry *)d_carry_out);
 }
 
 /* ------------------------------------------------------------------ CRC32 */

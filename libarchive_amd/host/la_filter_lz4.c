@@ -57,6 +57,9 @@ struct lz4_private {
 	struct lz4_slot slot[2];
 	int cur;
 	size_t batch_bytes;
+	la_lz4_resume rs;	/* a frame of independent blocks may span windows: where the walker is */
+	uint8_t *d_carry;	/* 2 x LA_XXH_CARRY_BYTES on the device: content-hash state from window to window */
+	int carry_flip;		/* which half the next window reads */
 	int upstream_eof;
 	int upstream_fatal;	/* upstream failed while the NEXT window was gathered: reported after this one */
 	/* host copies of per-unit results (only fetched when a batch has an event) */
@@ -129,6 +132,14 @@ static int lz4_reader_init(struct archive_read_filter *self)
 		free(st);
 		return ARCHIVE_FATAL;
 	}
+	void *cp = NULL;
+	if (la_gpu_malloc(st->gpu, &cp, 2 * LA_XXH_CARRY_BYTES) != LA_OK) {
+		archive_set_error(&self->archive->archive, ARCHIVE_ERRNO_MISC, "Can't allocate lz4 GPU state");
+		la_gpu_close(st->gpu);
+		free(st);
+		return ARCHIVE_FATAL;
+	}
+	st->d_carry = cp;
 	self->data = st;
 	self->vtable = &lz4_reader_vtable;
 	return ARCHIVE_OK;
@@ -219,14 +230,16 @@ static int lz4_gather_and_index(struct archive_read_filter *self, struct lz4_pri
 		}
 
 		/* 2. frame / block headers (host pointer chase, no payload byte touched) */
-		if (la_lz4_index_build(sl->stage, sl->stage_len, st->upstream_eof, &sl->idx) != 0) {
+		const la_lz4_resume rs_before = st->rs;
+		if (la_lz4_index_build2(sl->stage, sl->stage_len, st->upstream_eof, &st->rs, &sl->idx) != 0) {
 			archive_set_error(&self->archive->archive, ENOMEM, "Can't allocate data for lz4 decompression");
 			return ARCHIVE_FATAL;
 		}
-		if (sl->idx.end_kind == LA_END_NEED_MORE && sl->idx.n_blocks == 0 && sl->idx.n_frames == 0 &&
-		    sl->idx.consumed == 0) {
-			/* a single frame larger than the window: widen the window and gather more */
+		if (sl->idx.end_kind == LA_END_NEED_MORE && sl->idx.consumed == 0) {
+			/* not one complete item in the window (a block larger than it, or a whole frame of
+			 * dependent blocks): widen the window and gather more */
 			la_lz4_index_free(&sl->idx);
+			st->rs = rs_before;
 			st->batch_bytes *= 2;
 			continue;
 		}
@@ -283,8 +296,12 @@ static int lz4_launch(struct archive_read_filter *self, struct lz4_private *st, 
 	bt.d_block_status = (uint32_t *)(T + sl->o_bst);
 	bt.d_frame_status = (uint32_t *)(T + sl->o_fst);
 	bt.d_summary = (la_batch_summary *)(T + o_sum);
+	bt.d_carry_in = st->d_carry + (st->carry_flip ? LA_XXH_CARRY_BYTES : 0);
+	bt.d_carry_out = st->d_carry + (st->carry_flip ? 0 : LA_XXH_CARRY_BYTES);
 	if (la_gpu_lz4_decode(st->gpu, &bt) != LA_OK)
 		return gpu_fail(self, st, "la_gpu_lz4_decode");
+	if (nf && (x->frames[nf - 1].flags & LA_LZ4F_OPEN))
+		st->carry_flip ^= 1;	/* the next window continues this frame's content hash */
 	if (la_gpu_memcpy_d2h(st->gpu, sl->h_sum, T + o_sum, sizeof(*sl->h_sum)) != LA_OK)
 		return gpu_fail(self, st, "summary copy");
 	sl->launched = 1;
@@ -475,6 +492,7 @@ static int lz4_filter_close(struct archive_read_filter *self)
 			if (sl->d_dst) la_gpu_free(st->gpu, sl->d_dst);
 			if (sl->d_tabs) la_gpu_free(st->gpu, sl->d_tabs);
 		}
+		if (st->d_carry) la_gpu_free(st->gpu, st->d_carry);
 		la_gpu_close(st->gpu);
 	}
 	free(st->h_u32);

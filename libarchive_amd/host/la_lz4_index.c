@@ -80,25 +80,49 @@ void la_lz4_index_free(la_lz4_index *x)
 
 int la_lz4_index_build(const uint8_t *img, uint64_t len, int at_eof, la_lz4_index *x)
 {
+	return la_lz4_index_build2(img, len, at_eof, NULL, x);
+}
+
+int la_lz4_index_build2(const uint8_t *img, uint64_t len, int at_eof, la_lz4_resume *rs, la_lz4_index *x)
+{
 	uint64_t pos = 0;
 	memset(x, 0, sizeof(*x));
 	x->end_kind = LA_END_EOF;
+	int resume = rs && rs->in_frame;	/* the window starts inside a frame */
 
 	for (;;) {
 		/* lz4.c:328-364: select the next stream */
 		x->consumed = pos;
-		if (len - pos < 4)
-			SHORT(LA_END_EOF);
-		uint32_t m = le32(img + pos);
+		uint32_t m;
+		if (resume)
+			m = LZ4_MAGIC;
+		else {
+			if (len - pos < 4)
+				SHORT(LA_END_EOF);
+			m = le32(img + pos);
+		}
 		if (m == LZ4_MAGIC) {
 			uint64_t p = pos + 4;
+			uint32_t bmax, dbytes = 0, bsum;
+			int indep, ssum, cont = resume;
+			uint32_t blocks_before = 0;
+			resume = 0;
+			if (cont) {
+				/* continuation of a frame that began in an earlier window */
+				p = pos;
+				bmax = rs->bmax;
+				indep = 1;
+				bsum = (rs->flags & 1u) ? 4 : 0;
+				ssum = (rs->flags & 2u) != 0;
+				blocks_before = rs->blocks_so_far;
+				rs->in_frame = 0;
+			} else {
 			if (len - p < 2)
 				SHORT(LA_END_TRUNCATED);
 			uint8_t flag = img[p], bd = img[p + 1];
 			if ((flag & 0xc0) != 0x40 || (flag & 0x02) || (bd & 0x8f)) {
 				x->end_kind = LA_END_MALFORMED; goto out;
 			}
-			uint32_t bmax;
 			switch (bd >> 4) {
 			case 4: bmax = 64u << 10; break;
 			case 5: bmax = 256u << 10; break;
@@ -106,12 +130,13 @@ int la_lz4_index_build(const uint8_t *img, uint64_t len, int at_eof, la_lz4_inde
 			case 7: bmax = 4u << 20; break;
 			default: x->end_kind = LA_END_MALFORMED; goto out;
 			}
-			uint32_t dbytes = 3 + ((flag & 0x08) ? 8 : 0) + ((flag & 0x01) ? 4 : 0);
+			dbytes = 3 + ((flag & 0x08) ? 8 : 0) + ((flag & 0x01) ? 4 : 0);
 			if (len - p < dbytes)
 				SHORT(LA_END_TRUNCATED);
-			int indep = (flag & 0x20) != 0;
-			uint32_t bsum = (flag & 0x10) ? 4 : 0;
-			int ssum = (flag & 0x04) != 0;
+			indep = (flag & 0x20) != 0;
+			bsum = (flag & 0x10) ? 4 : 0;
+			ssum = (flag & 0x04) != 0;
+			}
 
 			/* tentatively index the frame; roll back if the window ends inside it */
 			uint32_t save_b = x->n_blocks, save_f = x->n_frames;
@@ -119,10 +144,10 @@ int la_lz4_index_build(const uint8_t *img, uint64_t len, int at_eof, la_lz4_inde
 			la_lz4_frame *f = push_frame(x);
 			if (!f) return -1;
 			uint32_t fi = x->n_frames - 1;
-			f->desc_off = p;
+			f->desc_off = cont ? 0 : p;
 			f->desc_len = dbytes;
 			f->first_block = x->n_blocks;
-			f->flags = LA_LZ4F_HEADER_SUM | (ssum ? LA_LZ4F_CONTENT_SUM : 0);
+			f->flags = (cont ? LA_LZ4F_CONT : LA_LZ4F_HEADER_SUM) | (ssum ? (LA_LZ4F_CONTENT_SUM | LA_LZ4F_HASHED) : 0);
 			p += dbytes;
 			int end = -1;
 			for (;;) {
@@ -132,7 +157,12 @@ int la_lz4_index_build(const uint8_t *img, uint64_t len, int at_eof, la_lz4_inde
 				if (w == 0) {
 					p += 4;
 					if (ssum) {
-						if (len - p < 4) { end = LA_END_TRUNCATED; break; }
+						if (len - p < 4) {
+							end = LA_END_TRUNCATED;
+							if (!at_eof)
+								p -= 4;	/* the EndMark is read again with the next window */
+							break;
+						}
 						x->frames[fi].content_sum = le32(img + p);
 						p += 4;
 					}
@@ -154,6 +184,18 @@ int la_lz4_index_build(const uint8_t *img, uint64_t len, int at_eof, la_lz4_inde
 				x->frames[fi].n_blocks++;
 			}
 			if (end >= 0) {
+				if (!at_eof && rs && indep) {
+					/* the frame goes on in the next window: its complete blocks are decoded
+					 * now, the content hash is carried over */
+					x->frames[fi].flags = (x->frames[fi].flags & ~LA_LZ4F_CONTENT_SUM) | LA_LZ4F_OPEN;
+					rs->in_frame = 1;
+					rs->bmax = bmax;
+					rs->flags = (bsum ? 1u : 0u) | (ssum ? 2u : 0u);
+					rs->blocks_so_far = blocks_before + x->frames[fi].n_blocks;
+					x->end_kind = LA_END_NEED_MORE;
+					x->consumed = p;
+					goto out;
+				}
 				if (!at_eof) {
 					/* incomplete frame in a window: hand the whole frame to the next window */
 					x->n_blocks = save_b; x->n_frames = save_f; x->max_out = save_out;
@@ -168,7 +210,7 @@ int la_lz4_index_build(const uint8_t *img, uint64_t len, int at_eof, la_lz4_inde
 				goto out;
 			}
 			pos = p;
-			if (x->frames[fi].n_blocks == 0) {
+			if (x->frames[fi].n_blocks == 0 && blocks_before == 0) {
 				x->consumed = pos;
 				x->end_kind = LA_END_EMPTY_FRAME;
 				goto out;

@@ -13,8 +13,9 @@
 #include <string.h>
 
 struct la_gpu_ctx { char err[64]; };
+_Static_assert(sizeof(orc_xxh32_state) <= LA_XXH_CARRY_BYTES, "carry buffer too small for the oracle's state");
 
-int la_gpu_abi_version(void) { return 1; }
+int la_gpu_abi_version(void) { return 2; }
 int la_gpu_device_count(void) { return 1; }
 int la_gpu_open(int device, la_gpu_ctx **out)
 {
@@ -94,9 +95,17 @@ int la_gpu_lz4_decode(la_gpu_ctx *c, const la_lz4_batch *bt)
 			if (((orc_xxh32(d, f->desc_len - 1, 0) >> 8) & 0xff) != d[f->desc_len - 1])
 				st = LA_ST_LZ4_BAD_HEADER_SUM;
 		}
-		if (verify && st == LA_ST_OK && (f->flags & LA_LZ4F_CONTENT_SUM)) {
+		if (verify && st == LA_ST_OK && (f->flags & LA_LZ4F_HASHED)) {
 			const uint64_t a = bt->d_dst_off[f->first_block], e = bt->d_dst_off[f->first_block + f->n_blocks];
-			if (orc_xxh32(bt->d_dst + a, (size_t)(uint32_t)(e - a), 0) != f->content_sum)
+			orc_xxh32_state hs;
+			if (f->flags & LA_LZ4F_CONT)
+				memcpy(&hs, bt->d_carry_in, sizeof(hs));
+			else
+				orc_xxh32_init(&hs, 0);
+			orc_xxh32_update(&hs, bt->d_dst + a, (size_t)(e - a));
+			if (f->flags & LA_LZ4F_OPEN)
+				memcpy(bt->d_carry_out, &hs, sizeof(hs));
+			else if ((f->flags & LA_LZ4F_CONTENT_SUM) && orc_xxh32_digest(&hs) != f->content_sum)
 				st = LA_ST_LZ4_BAD_CONTENT_SUM;
 		}
 		bt->d_frame_status[k] = st;

@@ -79,6 +79,47 @@ def test_lz4_multiple_batches(gpu_ctx, monkeypatch):
     assert la_api.as_reference_tuple(la_api.cat(bytes(bad), read_size=65536)) == ref
 
 
+def test_lz4_frame_larger_than_the_window(gpu_ctx, monkeypatch):
+    """ONE frame of many independent blocks, several times the gather window: the walker hands
+    out the complete blocks window by window (frame records flagged OPEN / CONT) and the content
+    hash state travels from window to window; output, return code and error string must be the
+    reference's, also when the frame is damaged or cut somewhere in the middle."""
+    import random
+    import oracle_lib as O
+    import streams as S
+    monkeypatch.setenv("LA_GPU_BATCH_MIB", "1")
+    rnd = random.Random(77)
+    for flg in (0x74, 0x64, 0x70, 0x60):        # with / without block and content checksums
+        words = [rnd.randbytes(rnd.randint(2, 9)) for _ in range(400)]
+        blocks = []
+        for k in range(200):
+            n = rnd.choice([65536, 65536, 30000])
+            d = b"".join(rnd.choice(words) for _ in range(n // 4 + 1))[:n] if k % 3 else bytes([k]) * 65536
+            blocks.append((d, S.lz4_block(S.lz4_compress_block(d), bsum=bool(flg & 0x10))))
+        img, plain = S.lz4_frame(blocks, flg=flg)
+        assert len(img) > 3 << 20 and len(plain) > 8 << 20
+        tail, tplain = S.synth_lz4_stream(9, 0, 2, blocks_per_frame=3, block_size=4096, nthreads=1)
+        whole = img + tail.tobytes()
+        for variant in range(5):
+            m = bytearray(whole)
+            if variant == 1:
+                m[len(img) // 2] ^= 0x20            # damage in the middle of the big frame
+            elif variant == 2:
+                m = m[:len(img) * 2 // 3]           # cut inside the big frame
+            elif variant == 3:
+                m[len(img) - 2] ^= 0x01             # its content checksum (or last block) is wrong
+            elif variant == 4:
+                m = m[:len(img) - 3]                # cut inside the trailer of the big frame
+            m = bytes(m)
+            out, res = O.lz4_stream_decode(m, 1 << 27)
+            want = (out.tobytes(), res.rc, res.errmsg.decode())
+            r = la_api.cat(m, read_size=rnd.choice([None, 65536, 7777]))
+            got = la_api.as_reference_tuple(r)
+            assert got == want, (hex(flg), variant, len(got[0]), len(want[0]), got[1:], want[1:])
+            if variant == 0:
+                assert len(r.block_sizes) >= 3      # really delivered window by window
+
+
 def test_lz4_file_reader(gpu_ctx, tmp_path):
     img, plain = S.synth_lz4_stream(8, 0, 6, blocks_per_frame=4, block_size=65536, nthreads=2)
     f = tmp_path / "x.lz4"

@@ -33,7 +33,7 @@ def gpu_decode(ctx, image, options=None):
 
 def test_library_is_loaded_and_device_present(gpu_ctx):
     import libarchive_amd as la
-    assert la.gpu_lib().la_gpu_abi_version() == 1
+    assert la.gpu_lib().la_gpu_abi_version() == 2
     assert la.gpu_lib().la_gpu_device_count() >= 1
 
 

@@ -51,7 +51,7 @@ def test_walker_flags_and_layout():
     assert idx.consumed == img.size and idx.max_out == 12 * 65536
     assert np.all(idx.blocks["flags"][[0, 4, 8]] & N.LA_LZ4B_FIRST)
     assert np.all((idx.blocks["flags"] & N.LA_LZ4B_CHECKSUM) != 0)
-    assert np.all(idx.frames["flags"] == (N.LA_LZ4F_CONTENT_SUM | N.LA_LZ4F_HEADER_SUM))
+    assert np.all(idx.frames["flags"] == (N.LA_LZ4F_CONTENT_SUM | N.LA_LZ4F_HEADER_SUM | N.LA_LZ4F_HASHED))
     out, rc, msg, _ = host_decode(img)
     assert rc == 0 and out == plain.tobytes()
     ref, res = O.lz4_stream_decode(img, plain.size + 16)
