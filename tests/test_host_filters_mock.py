@@ -60,7 +60,7 @@ def test_lz4_window_pipeline_fuzz(gpu_ctx, monkeypatch):
     import streams as S
     monkeypatch.setenv("LA_GPU_BATCH_MIB", "1")
     rnd = random.Random(2024)
-    for t in range(30):
+    for t in range(80):
         nfr = rnd.randint(3, 14)
         img, plain = S.synth_lz4_stream(100 + t, 0, nfr, blocks_per_frame=rnd.choice([1, 4, 7]),
                                         block_size=rnd.choice([4096, 30000, 65536]), nthreads=2)
@@ -78,3 +78,41 @@ def test_lz4_window_pipeline_fuzz(gpu_ctx, monkeypatch):
         for rs in (None, 65536, 1000):
             got = la_api.as_reference_tuple(la_api.cat(m, read_size=rs))
             assert got == want, (t, how, rs)
+
+
+def test_gzip_window_fuzz(gpu_ctx, monkeypatch):
+    """Multi-member gzip streams several windows long (1 MiB windows), members of all sizes up to
+    a few hundred KiB, header variants, mutations / truncations / junk: bytes, return code and
+    error string must be the reference's (64 KiB delivery rule included)."""
+    import random
+    import zlib
+    import oracle_lib as O
+    import streams as S
+    monkeypatch.setenv("LA_GPU_BATCH_MIB", "1")
+    rnd = random.Random(4242)
+    words = [rnd.randbytes(rnd.randint(1, 10)) for _ in range(200)]
+    for t in range(80):
+        parts = []
+        for k in range(rnd.randint(2, 30)):
+            n = rnd.choice([0, 1, 500, 20000, 65536, 70000, rnd.randint(0, 300000)])
+            kind = rnd.randrange(3)
+            d = (b"".join(rnd.choice(words) for _ in range(n // 5 + 1))[:n] if kind == 0 else
+                 rnd.randbytes(n) if kind == 1 else bytes([k]) * n)
+            parts.append(S.gz_member(d, level=rnd.choice([0, 1, 6, 9]), name=b"n%d" % k if rnd.random() < 0.3 else None))
+        m = bytearray(b"".join(parts))
+        how = rnd.randrange(5)
+        if how == 1:
+            m[rnd.randrange(len(m))] ^= 1 << rnd.randrange(8)
+        elif how == 2:
+            m = m[:rnd.randrange(1, len(m))]
+        elif how == 3:
+            m += rnd.randbytes(rnd.randint(1, 20))
+        elif how == 4 and len(parts) > 2:
+            cut = len(parts[0]) + len(parts[1]) // 2
+            m[cut] ^= 0x04
+        m = bytes(m)
+        out, res = O.gzip_stream_decode(m, 1 << 27)
+        want = (out.tobytes(), res.rc, res.errmsg.decode())
+        for rs in (None, 4096):
+            got = la_api.as_reference_tuple(la_api.cat(m, read_size=rs))
+            assert got == want, (t, how, rs, len(got[0]), len(want[0]), got[1:], want[1:])
