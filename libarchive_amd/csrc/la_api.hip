@@ -423,7 +423,9 @@ int la_gpu_lz4_decode(la_gpu_ctx *c, const la_lz4_batch *bt)
 			/* frames that END in this slice: all their blocks are in the slab now */
 			la_launch_lz4_frame_sums(sp, bt->d_src, bt->d_dst, bt->d_frames, bt->n_frames,
 			    bt->d_dst_off, bt->dst_cap, bt->d_frame_status, i ? first + 1 : 0u, last,
-			    bt->d_carry_in, bt->d_carry_out);
+			    bt->d_carry_in, bt->d_carry_out,
+			    /* nothing overlaps the last slice's hashes (nor a small batch's): the low-latency form */
+			    i + 1 == nsl);
 			prof_close(c, h, sp);
 		}
 	}

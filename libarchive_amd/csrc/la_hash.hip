@@ -155,16 +155,21 @@ __device__ uint32_t xxh32_quad_stream(const la_xxh_carry *cin, la_xxh_carry *cou
 	return xxh_avalanche(h);
 }
 
+/* ROW = false: four lanes per frame (xxh32_quad; bulk).  ROW = true: sixteen lanes per frame
+ * (xxh32_row; half the latency per hash, a quarter of the hashes per instruction) for launches
+ * whose duration nothing hides. */
+template <bool ROW>
 __global__ __launch_bounds__(64) void lz4_frame_sums_kernel(const uint8_t *__restrict__ src,
     const uint8_t *__restrict__ dst, const la_lz4_frame *__restrict__ frames, uint32_t n,
     const uint64_t *__restrict__ dst_off, uint64_t dst_cap, uint32_t *__restrict__ fstatus,
     uint32_t end_lo, uint32_t end_hi, const la_xxh_carry *carry_in, la_xxh_carry *carry_out)
 {
 	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-	uint32_t i = t >> 2;
-	int j = (int)(t & 3);
+	uint32_t i = ROW ? t >> 4 : t >> 2;
+	const int l = (int)(t & (ROW ? 15u : 3u));
+	int j = l & 3;
 	if (i >= n)
-		return;		/* n is rounded so that whole quads leave together */
+		return;		/* n is rounded so that whole quads / rows leave together */
 	la_lz4_frame f = frames[i];
 	/* this launch takes the frames whose LAST block index + 1 lies in [end_lo, end_hi]
 	 * (the batch is expanded in slices; a frame is hashed once all its blocks exist) */
@@ -192,12 +197,12 @@ __global__ __launch_bounds__(64) void lz4_frame_sums_kernel(const uint8_t *__res
 		uint64_t a = dst_off[f.first_block], e = dst_off[f.first_block + f.n_blocks];
 		if (e <= dst_cap) {
 			/* xxhash.c:234: the length is an unsigned int there */
-			uint32_t h = xxh32_quad(dst + a, (uint32_t)(e - a), 0, j);
+			uint32_t h = ROW ? xxh32_row(dst + a, (uint32_t)(e - a), 0, l) : xxh32_quad(dst + a, (uint32_t)(e - a), 0, j);
 			if (h != f.content_sum)
 				st = LA_ST_LZ4_BAD_CONTENT_SUM;
 		}
 	}
-	if (j == 0)
+	if (l == 0)
 		fstatus[i] = st;
 }
 
@@ -217,12 +222,18 @@ void la_launch_lz4_block_sums(hipStream_t s, const uint8_t *d_src, const la_lz4_
 
 void la_launch_lz4_frame_sums(hipStream_t s, const uint8_t *d_src, const uint8_t *d_dst,
     const la_lz4_frame *d_frames, uint32_t n_frames, const uint64_t *d_dst_off, uint64_t dst_cap,
-    uint32_t *d_frame_status, uint32_t end_lo, uint32_t end_hi, const void *d_carry_in, void *d_carry_out)
+    uint32_t *d_frame_status, uint32_t end_lo, uint32_t end_hi, const void *d_carry_in, void *d_carry_out,
+    int row)
 {
 	if (n_frames == 0) return;
-	hipLaunchKernelGGL(lz4_frame_sums_kernel, dim3((n_frames + 15) / 16), dim3(64), 0, s,
-	    d_src, d_dst, d_frames, n_frames, d_dst_off, dst_cap, d_frame_status, end_lo, end_hi,
-	    (const la_xxh_carry *)d_carry_in, (la_xxh_carry *)d_carry_out);
+	if (row)
+		hipLaunchKernelGGL(lz4_frame_sums_kernel<true>, dim3((n_frames + 3) / 4), dim3(64), 0, s,
+		    d_src, d_dst, d_frames, n_frames, d_dst_off, dst_cap, d_frame_status, end_lo, end_hi,
+		    (const la_xxh_carry *)d_carry_in, (la_xxh_carry *)d_carry_out);
+	else
+		hipLaunchKernelGGL(lz4_frame_sums_kernel<false>, dim3((n_frames + 15) / 16), dim3(64), 0, s,
+		    d_src, d_dst, d_frames, n_frames, d_dst_off, dst_cap, d_frame_status, end_lo, end_hi,
+		    (const la_xxh_carry *)d_carry_in, (la_xxh_carry *)d_carry_out);
 }
 
 /* ------------------------------------------------------------------ CRC32 */
