@@ -156,6 +156,7 @@ __device__ __forceinline__ uint32_t xxh32_quad(const uint8_t *p, uint32_t len, u
  * instead of two, 29 instead of 62 cycles per stripe.  Only a quarter as many hashes share an
  * instruction, so this form is for hashes nothing else hides (the last slice of a batch, frames
  * that cross batches), not for bulk.  Result valid in lanes 0..3 of the row. */
+#define XXH_ROW_BATCH 32
 __device__ __forceinline__ uint32_t xxh_chain_step(uint32_t v, uint32_t prod)
 {
 	return rotl32(v + prod, 13) * XXH_P1;
@@ -168,8 +169,9 @@ __device__ __forceinline__ uint32_t xxh32_row(const uint8_t *p, uint32_t len, ui
 	if (len >= 16) {
 		uint32_t v = (j == 0) ? seed + XXH_P1 + XXH_P2 : (j == 1) ? seed + XXH_P2 : (j == 2) ? seed : seed - XXH_P1;
 		const uint8_t *q = p + 4 * l;
-		/* eight groups of four stripes per batch; the next batch is requested before this one
-		 * is chained */
+		/* XXH_ROW_BATCH groups of four stripes per batch (2 KiB per row); the next batch is
+		 * requested before this one is chained, and chaining a batch takes about as long as a
+		 * load does */
 #define XXH_ROW_CHAIN(xg_)                                                                                        \
 		do {                                                                                              \
 			const uint32_t pr_ = (xg_) * XXH_P2;                                                      \
@@ -178,27 +180,27 @@ __device__ __forceinline__ uint32_t xxh32_row(const uint8_t *p, uint32_t len, ui
 			v = xxh_chain_step(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pr_, 0x108, 0xf, 0xf, false));	/* row_shl:8 */ \
 			v = xxh_chain_step(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pr_, 0x10c, 0xf, 0xf, false));	/* row_shl:12 */ \
 		} while (0)
-		if (p + 512 <= end) {
-			uint32_t x[8];
+		if (p + XXH_ROW_BATCH * 64 <= end) {
+			uint32_t x[XXH_ROW_BATCH];
 #pragma unroll
-			for (int g = 0; g < 8; g++)
+			for (int g = 0; g < XXH_ROW_BATCH; g++)
 				x[g] = ld_u32(q + 64 * g);
-			p += 512; q += 512;
-			while (p + 512 <= end) {
-				uint32_t y[8];
+			p += XXH_ROW_BATCH * 64; q += XXH_ROW_BATCH * 64;
+			while (p + XXH_ROW_BATCH * 64 <= end) {
+				uint32_t y[XXH_ROW_BATCH];
 #pragma unroll
-				for (int g = 0; g < 8; g++)
+				for (int g = 0; g < XXH_ROW_BATCH; g++)
 					y[g] = ld_u32(q + 64 * g);
 #pragma unroll
-				for (int g = 0; g < 8; g++)
+				for (int g = 0; g < XXH_ROW_BATCH; g++)
 					XXH_ROW_CHAIN(x[g]);
 #pragma unroll
-				for (int g = 0; g < 8; g++)
+				for (int g = 0; g < XXH_ROW_BATCH; g++)
 					x[g] = y[g];
-				p += 512; q += 512;
+				p += XXH_ROW_BATCH * 64; q += XXH_ROW_BATCH * 64;
 			}
 #pragma unroll
-			for (int g = 0; g < 8; g++)
+			for (int g = 0; g < XXH_ROW_BATCH; g++)
 				XXH_ROW_CHAIN(x[g]);
 		}
 		while (p + 64 <= end) {
