@@ -78,8 +78,12 @@ static_assert(sizeof(la_xxh_carry) == LA_XXH_CARRY_BYTES, "carry record size");
  * the next one (cout != NULL).  Four lanes per hash as in xxh32_quad: lane j owns accumulator
  * j.  Returns the digest when cout == NULL (valid in all four lanes).
  */
-__device__ uint32_t xxh32_quad_stream(const la_xxh_carry *cin, la_xxh_carry *cout, const uint8_t *p, uint64_t n, int j)
+/* ROW: called by the sixteen lanes of a DPP row (l = 0..15, accumulator j = l & 3 valid in lanes
+ * 0..3) -- the stripes are then chained as in xxh32_row; otherwise by the four lanes of a quad. */
+template <bool ROW>
+__device__ uint32_t xxh32_quad_stream(const la_xxh_carry *cin, la_xxh_carry *cout, const uint8_t *p, uint64_t n, int l)
 {
+	const int j = l & 3;
 	uint32_t v = (j == 0) ? XXH_P1 + XXH_P2 : (j == 1) ? XXH_P2 : (j == 2) ? 0u : 0u - XXH_P1;
 	uint32_t msz = 0;
 	uint64_t total = 0;
@@ -109,7 +113,48 @@ __device__ uint32_t xxh32_quad_stream(const la_xxh_carry *cin, la_xxh_carry *cou
 		}
 		const uint8_t *q = p + 4 * j;
 		uint64_t left = n;
-		while (left >= 512) {	/* 32 stripes of loads in flight per quad, as in xxh32_quad */
+		if (ROW) {
+			/* groups of four stripes, lane l takes dword l of each 64-byte group (xxh32_row) */
+			const uint8_t *qr = p + 4 * l;
+#define XXH_ROW_CHAIN(xg_)                                                                                        \
+			do {                                                                                      \
+				const uint32_t pr_ = (xg_) * XXH_P2;                                              \
+				v = xxh_chain_step(v, pr_);                                                       \
+				v = xxh_chain_step(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pr_, 0x104, 0xf, 0xf, false)); \
+				v = xxh_chain_step(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pr_, 0x108, 0xf, 0xf, false)); \
+				v = xxh_chain_step(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pr_, 0x10c, 0xf, 0xf, false)); \
+			} while (0)
+			if (left >= XXH_ROW_BATCH * 64) {
+				uint32_t x[XXH_ROW_BATCH];
+#pragma unroll
+				for (int g = 0; g < XXH_ROW_BATCH; g++)
+					x[g] = ld_u32(qr + 64 * g);
+				qr += XXH_ROW_BATCH * 64; left -= XXH_ROW_BATCH * 64;
+				while (left >= XXH_ROW_BATCH * 64) {
+					uint32_t y[XXH_ROW_BATCH];
+#pragma unroll
+					for (int g = 0; g < XXH_ROW_BATCH; g++)
+						y[g] = ld_u32(qr + 64 * g);
+#pragma unroll
+					for (int g = 0; g < XXH_ROW_BATCH; g++)
+						XXH_ROW_CHAIN(x[g]);
+#pragma unroll
+					for (int g = 0; g < XXH_ROW_BATCH; g++)
+						x[g] = y[g];
+					qr += XXH_ROW_BATCH * 64; left -= XXH_ROW_BATCH * 64;
+				}
+#pragma unroll
+				for (int g = 0; g < XXH_ROW_BATCH; g++)
+					XXH_ROW_CHAIN(x[g]);
+			}
+			while (left >= 64) {
+				XXH_ROW_CHAIN(ld_u32(qr));
+				qr += 64; left -= 64;
+			}
+#undef XXH_ROW_CHAIN
+			q = p + (n - left) + 4 * j;	/* the last (fewer than four) stripes: lanes 0..3 on their own */
+		}
+		while (!ROW && left >= 512) {	/* 32 stripes of loads in flight per quad, as in xxh32_quad */
 			uint32_t x[32];
 #pragma unroll
 			for (int t = 0; t < 32; t++)
@@ -128,8 +173,9 @@ __device__ uint32_t xxh32_quad_stream(const la_xxh_carry *cin, la_xxh_carry *cou
 		msz = (uint32_t)left;
 	}
 	if (cout) {
-		cout->v[j] = v;
-		if (j == 0) {
+		if (l < 4)	/* (in the row form only lanes 0..3 hold accumulators) */
+			cout->v[j] = v;
+		if (l == 0) {
 			cout->memsize = msz;
 			cout->total_lo = (uint32_t)total;
 			cout->total_hi = (uint32_t)(total >> 32);
@@ -187,8 +233,8 @@ __global__ __launch_bounds__(64) void lz4_frame_sums_kernel(const uint8_t *__res
 		if ((f.flags & LA_LZ4F_HASHED) && carry_in && carry_out) {
 			uint64_t a = dst_off[f.first_block], e = dst_off[f.first_block + f.n_blocks];
 			if (e <= dst_cap) {
-				const uint32_t h = xxh32_quad_stream((f.flags & LA_LZ4F_CONT) ? carry_in : nullptr,
-				    (f.flags & LA_LZ4F_OPEN) ? carry_out : nullptr, dst + a, e - a, j);
+				const uint32_t h = xxh32_quad_stream<ROW>((f.flags & LA_LZ4F_CONT) ? carry_in : nullptr,
+				    (f.flags & LA_LZ4F_OPEN) ? carry_out : nullptr, dst + a, e - a, l);
 				if (!(f.flags & LA_LZ4F_OPEN) && (f.flags & LA_LZ4F_CONTENT_SUM) && h != f.content_sum)
 					st = LA_ST_LZ4_BAD_CONTENT_SUM;
 			}
