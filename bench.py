@@ -275,8 +275,10 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
         if os.path.exists(tpath) and abs(args.gib - 16.0) < 1e-6 and not args.general_only:
             # PMC-measured HBM bytes of the expand kernel for this exact workload (separate
-            # rocprofv3 --pmc passes, committed under profiles/), summed over its slice launches
-            traffic = json.load(open(tpath))["lz4_expand_fast_kernel"]["hbm_bytes_per_step"]
+            # rocprofv3 --pmc passes, committed under profiles/), per slice launch like `achieved`
+            traffic = json.load(open(tpath))["lz4_expand_fast_kernel"]["hbm_bytes_per_launch"]
+        nl = 4 if (plan.n_blocks >= 32768 and not args.general_only) else 1   # slice launches of the expand kernel per step
+        # per-launch algorithmic bytes / per-launch duration (the slices are equal, so this is the ratio of the sums)
         achieved = (C_bytes + U_bytes) / (exp_ms * 1e-3) / 1e9
         step_ms = dt_max / args.steps * 1e3
         line = {
@@ -314,8 +316,9 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
-                "algorithmic_bytes": C_bytes + U_bytes,
-                "launches_per_step": 4 if (plan.n_blocks >= 32768 and not args.general_only) else 1,
+                "launches_per_step": nl,
+                "algorithmic_bytes": (C_bytes + U_bytes) // nl,   # per launch, like traffic and achieved
+                "launch_ms": round(exp_ms / nl, 4),
                 "whole_step_frac": round((C_bytes + U_bytes) / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             },
             "cpu_baseline": cpu,
