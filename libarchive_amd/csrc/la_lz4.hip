@@ -375,7 +375,16 @@ __global__ __launch_bounds__(256) void lz4_expand_general_kernel(const uint8_t *
 		    !(fast_max_seq && la_lz4_fast_eligible(b) && nseq[i] <= fast_max_seq)) {
 			const uint8_t *s = src + b.src_off;
 			if (b.flags & LA_LZ4B_STORED) {
-				for (uint32_t j = (uint32_t)lane; j < b.src_len; j += LA_WAVE)
+				/* stored block (lz4.c:530-552): bytes up to the slab's 16-byte grid one by one,
+				 * then 1 KiB per wave and pass (unaligned 16-byte loads, aligned stores) */
+				uint32_t head = (16u - (uint32_t)((uintptr_t)d & 15u)) & 15u;
+				if (head > b.src_len) head = b.src_len;
+				if ((uint32_t)lane < head)
+					d[lane] = s[lane];
+				const uint32_t nvec = (b.src_len - head) >> 4;
+				for (uint32_t j = (uint32_t)lane; j < nvec; j += LA_WAVE)
+					*(uint4 *)(d + head + 16u * j) = ld_u128(s + head + 16u * j);
+				for (uint32_t j = head + (nvec << 4) + (uint32_t)lane; j < b.src_len; j += LA_WAVE)
 					d[j] = s[j];
 			} else {
 				uint32_t dict_len = 0;
