@@ -23,6 +23,7 @@
  * Environment (read filters take no options, archive_read_set_options.c:110-123):
  *   LA_GPU_DEVICE     device ordinal (default 0)
  *   LA_GPU_BATCH_MIB  compressed bytes gathered per batch (default 256)
+ *   LA_GPU_MAX_BATCH_MIB  how far a window of few, large blocks may grow (default 2048)
  */
 #include "la_read_private.h"
 #include "../../include/la_gpu.h"
@@ -56,7 +57,7 @@ struct lz4_private {
 	 * the order in which bytes and errors come out of read() does not change. */
 	struct lz4_slot slot[2];
 	int cur;
-	size_t batch_bytes;
+	size_t batch_bytes, max_batch_bytes;
 	la_lz4_resume rs;	/* a frame of independent blocks may span windows: where the walker is */
 	uint8_t *d_carry;	/* 2 x LA_XXH_CARRY_BYTES on the device: content-hash state from window to window */
 	int carry_flip;		/* which half the next window reads */
@@ -125,6 +126,8 @@ static int lz4_reader_init(struct archive_read_filter *self)
 	const char *dev = getenv("LA_GPU_DEVICE");
 	const char *bm = getenv("LA_GPU_BATCH_MIB");
 	st->batch_bytes = (size_t)(bm && atoi(bm) > 0 ? atoi(bm) : 256) << 20;
+	const char *bmx = getenv("LA_GPU_MAX_BATCH_MIB");
+	st->max_batch_bytes = (size_t)(bmx && atoi(bmx) > 0 ? atoi(bmx) : 2048) << 20;
 	int rc = la_gpu_open(dev ? atoi(dev) : 0, &st->gpu);
 	if (rc != LA_OK) {
 		archive_set_error(&self->archive->archive, ARCHIVE_ERRNO_MISC,
@@ -182,6 +185,7 @@ static int grow_dev(struct lz4_private *st, void **p, size_t *cap, size_t need)
 }
 
 #define ALIGN256(x) (((x) + 255) & ~(size_t)255)
+#define LA_LZ4_MIN_SLOW_BLOCKS 2048u	/* blocks above 64 KiB wanted in one window before it stops growing */
 
 /* what the index alone says about the end of the stream (no device verdict involved) */
 static void lz4_apply_end_kind(struct lz4_private *st, int end_kind)
@@ -242,6 +246,20 @@ static int lz4_gather_and_index(struct archive_read_filter *self, struct lz4_pri
 			st->rs = rs_before;
 			st->batch_bytes *= 2;
 			continue;
+		}
+		if (sl->idx.end_kind == LA_END_NEED_MORE && !st->upstream_eof && st->batch_bytes < st->max_batch_bytes) {
+			/* Blocks above 64 KiB are parsed by one lane and expanded by one wave each (about
+			 * 0.2 s per 4 MiB block, however many run side by side): their throughput is the
+			 * number of blocks in flight, so a window that holds only a few of them grows. */
+			uint32_t slow = 0;
+			for (uint32_t k = 0; k < sl->idx.n_blocks; k++)
+				slow += sl->idx.blocks[k].dst_cap > 65536u;
+			if (slow != 0 && slow < LA_LZ4_MIN_SLOW_BLOCKS) {
+				la_lz4_index_free(&sl->idx);
+				st->rs = rs_before;
+				st->batch_bytes *= 2;
+				continue;
+			}
 		}
 		sl->have_idx = 1;
 		return 0;

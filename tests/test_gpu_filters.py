@@ -120,6 +120,40 @@ def test_lz4_frame_larger_than_the_window(gpu_ctx, monkeypatch):
                 assert len(r.block_sizes) >= 3      # really delivered window by window
 
 
+def test_lz4_window_grows_for_large_blocks(gpu_ctx, monkeypatch):
+    """Frames of 1 MiB blocks behind a 1 MiB window that may grow to 4 MiB: blocks above 64 KiB
+    run one per lane / wave on the device, so the filter gathers more of them per window."""
+    import random
+    import oracle_lib as O
+    import streams as S
+    monkeypatch.setenv("LA_GPU_BATCH_MIB", "1")
+    monkeypatch.setenv("LA_GPU_MAX_BATCH_MIB", "4")
+    rnd = random.Random(5)
+    frames, plain = [], b""
+    for f in range(7):
+        blocks = []
+        for k in range(3):
+            d = rnd.randbytes(rnd.choice([1 << 20, 700000, 12345]))     # incompressible: stored-size payloads
+            blocks.append((d, S.lz4_block(d, stored=True, bsum=True)))
+        fr, pl = S.lz4_frame(blocks, flg=0x74, bd=0x60)
+        frames.append(fr)
+        plain += pl
+    img = b"".join(frames)
+    for variant in range(3):
+        m = bytearray(img)
+        if variant == 1:
+            m[len(m) // 2] ^= 0x08
+        elif variant == 2:
+            m = m[:len(m) * 3 // 5]
+        m = bytes(m)
+        out, res = O.lz4_stream_decode(m, 1 << 26)
+        want = (out.tobytes(), res.rc, res.errmsg.decode())
+        r = la_api.cat(m, read_size=65536)
+        assert la_api.as_reference_tuple(r) == want, variant
+        if variant == 0:
+            assert out.tobytes() == plain and 2 <= len(r.block_sizes) <= 8    # a few multi-MiB windows
+
+
 def test_lz4_file_reader(gpu_ctx, tmp_path):
     img, plain = S.synth_lz4_stream(8, 0, 6, blocks_per_frame=4, block_size=65536, nthreads=2)
     f = tmp_path / "x.lz4"
