@@ -34,8 +34,8 @@
  * HBM traffic per block: payload once, sequence table once in (plus the entries
  * phase L looks up), decoded bytes once out.
  *
- * What bounds it (PMC, C2 workload): the LDS pipe is 66 % busy, the SIMDs about
- * half, and behind both sits the dependency chain of phase M (DAG depth 16 per
+ * What bounds it (PMC, C2 workload): the LDS pipe is 58 % busy, the SIMDs a little
+ * under half, and behind both sits the dependency chain of phase M (DAG depth 16 per
  * block, about 31 poll iterations per wave).  What a poll iteration costs is LDS
  * round trips in series, LDS instructions, and VALU instructions, in that order.
  * Measured on the way here (16 GiB C2 stream, expand ms):
