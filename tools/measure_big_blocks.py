@@ -30,6 +30,10 @@ ctx = la.GpuContext(0); ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 d_src = torch.from_numpy(img).cuda()
 plan = Lz4DevicePlan(ctx, d_src, idx)
 plan.run(); ctx.sync()
+ctx.profile_enable(True)
+plan.run()
+print('phases (ms):', {k: round(v, 2) for k, v in ctx.profile_read()})
+ctx.profile_enable(False)
 t0 = time.time()
 for _ in range(3):
     plan.run()
