@@ -88,7 +88,8 @@ int la_lz4_index_build2(const uint8_t *img, uint64_t len, int at_eof, la_lz4_res
 	uint64_t pos = 0;
 	memset(x, 0, sizeof(*x));
 	x->end_kind = LA_END_EOF;
-	int resume = rs && rs->in_frame;	/* the window starts inside a frame */
+	int resume = rs && rs->in_frame == 1;	/* the window starts inside a frame */
+	int resume_legacy = rs && rs->in_frame == 2;	/* ... inside a legacy frame */
 
 	for (;;) {
 		/* lz4.c:328-364: select the next stream */
@@ -96,6 +97,8 @@ int la_lz4_index_build2(const uint8_t *img, uint64_t len, int at_eof, la_lz4_res
 		uint32_t m;
 		if (resume)
 			m = LZ4_MAGIC;
+		else if (resume_legacy)
+			m = LZ4_LEGACY;
 		else {
 			if (len - pos < 4)
 				SHORT(LA_END_EOF);
@@ -222,8 +225,15 @@ frame_cut:
 			x->frames[fi].flags &= ~LA_LZ4F_CONTENT_SUM;
 			goto out;
 		} else if (m == LZ4_LEGACY) {
-			/* lz4.c:670-721 */
-			uint64_t p = pos + 4;
+			/* lz4.c:670-721.  Legacy blocks share nothing (no checksums, no dictionary), so a
+			 * legacy frame larger than the window simply continues with the next window. */
+			const int cont = resume_legacy;
+			const uint32_t blocks_before = cont ? rs->blocks_so_far : 0;
+			uint64_t p = cont ? pos : pos + 4;
+			if (cont) {
+				resume_legacy = 0;
+				rs->in_frame = 0;
+			}
 			uint32_t save_b = x->n_blocks, save_f = x->n_frames;
 			uint64_t save_out = x->max_out;
 			la_lz4_frame *f = push_frame(x);
@@ -233,7 +243,7 @@ frame_cut:
 			int end = -1;
 			for (;;) {
 				if (len - p < 4) {
-					if (x->frames[fi].n_blocks == 0 || !at_eof)
+					if (x->frames[fi].n_blocks + blocks_before == 0 || !at_eof)
 						end = LA_END_TRUNCATED;	/* lz4.c:685-692 (first block) */
 					break;
 				}
@@ -253,6 +263,14 @@ frame_cut:
 				x->frames[fi].n_blocks++;
 			}
 			if (end >= 0) {
+				if (!at_eof && rs) {
+					/* the complete blocks are decoded now, the frame goes on in the next window */
+					rs->in_frame = 2;
+					rs->blocks_so_far = blocks_before + x->frames[fi].n_blocks;
+					x->end_kind = LA_END_NEED_MORE;
+					x->consumed = p;
+					goto out;
+				}
 				if (!at_eof) {
 					x->n_blocks = save_b; x->n_frames = save_f; x->max_out = save_out;
 					x->end_kind = LA_END_NEED_MORE;
@@ -263,7 +281,7 @@ frame_cut:
 				goto out;
 			}
 			pos = p;
-			if (x->frames[fi].n_blocks == 0) {
+			if (x->frames[fi].n_blocks + blocks_before == 0) {
 				/* legacy magic without a block: the read() that selected it returns 0 */
 				x->consumed = pos;
 				x->end_kind = LA_END_EOF;

@@ -154,6 +154,44 @@ def test_lz4_window_grows_for_large_blocks(gpu_ctx, monkeypatch):
             assert out.tobytes() == plain and 2 <= len(r.block_sizes) <= 8    # a few multi-MiB windows
 
 
+def test_lz4_legacy_frame_across_windows(gpu_ctx, monkeypatch):
+    """A legacy frame (magic 0x184C2102, blocks of up to 8 MiB, no checksums) several windows
+    long, followed by a modern frame; clean, damaged and cut."""
+    import random
+    import struct
+    import oracle_lib as O
+    import streams as S
+    monkeypatch.setenv("LA_GPU_BATCH_MIB", "1")
+    monkeypatch.setenv("LA_GPU_MAX_BATCH_MIB", "2")
+    rnd = random.Random(31)
+    words = [rnd.randbytes(rnd.randint(2, 9)) for _ in range(300)]
+    img, plain = S.LEGACY, b""
+    for k in range(14):
+        n = rnd.choice([1 << 20, 300000, 8 << 20]) if k != 13 else 12345      # the last block may be short
+        d = b"".join(rnd.choice(words) for _ in range(n // 4 + 1))[:n]
+        c = S.lz4_compress_block(d)
+        img += struct.pack("<I", len(c)) + c
+        plain += d
+    tail, tplain = S.synth_lz4_stream(3, 0, 2, blocks_per_frame=2, block_size=5000, nthreads=1)
+    whole = img + tail.tobytes()
+    assert len(img) > 3 << 20
+    for variant in range(4):
+        m = bytearray(whole)
+        if variant == 1:
+            m[len(img) // 2] ^= 0x40
+        elif variant == 2:
+            m = m[:len(img) * 2 // 3]
+        elif variant == 3:
+            m = m[:len(img)]                     # legacy frame alone: ends at the end of the input
+        m = bytes(m)
+        out, res = O.lz4_stream_decode(m, 1 << 28)
+        want = (out.tobytes(), res.rc, res.errmsg.decode())
+        got = la_api.as_reference_tuple(la_api.cat(m, read_size=rnd.choice([None, 65536])))
+        assert got == want, (variant, len(got[0]), len(want[0]), got[1:], want[1:])
+        if variant == 0:
+            assert got[0] == plain + tplain.tobytes()
+
+
 def test_lz4_file_reader(gpu_ctx, tmp_path):
     img, plain = S.synth_lz4_stream(8, 0, 6, blocks_per_frame=4, block_size=65536, nthreads=2)
     f = tmp_path / "x.lz4"

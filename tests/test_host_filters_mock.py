@@ -36,6 +36,7 @@ from test_gpu_filters import (  # noqa: E402,F401
     test_lz4_multiple_batches,
     test_lz4_frame_larger_than_the_window,
     test_lz4_window_grows_for_large_blocks,
+    test_lz4_legacy_frame_across_windows,
     test_lz4_file_reader,
     test_gzip_behaviour_table_through_the_api,
     test_gzip_metadata_snapshot,
