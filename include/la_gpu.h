@@ -59,6 +59,7 @@ int         la_gpu_malloc_host(la_gpu_ctx *ctx, void **h_ptr, uint64_t bytes);	/
 int         la_gpu_free_host(la_gpu_ctx *ctx, void *h_ptr);
 int         la_gpu_memcpy_h2d(la_gpu_ctx *ctx, void *d_dst, const void *h_src, uint64_t bytes);
 int         la_gpu_memcpy_d2h(la_gpu_ctx *ctx, void *h_dst, const void *d_src, uint64_t bytes);
+int         la_gpu_memcpy_d2d(la_gpu_ctx *ctx, void *d_dst, const void *d_src, uint64_t bytes);
 
 /* A marker in the stream: la_gpu_mark() notes the point reached so far, la_gpu_wait_mark()
  * blocks the host until everything queued BEFORE the marker is done -- work queued after it
@@ -125,6 +126,8 @@ int la_gpu_crc32_many(la_gpu_ctx *ctx, const uint8_t *d_base,
 #define LA_LZ4B_CHECKSUM  2u	/* block_sum holds the LE32 that followed the payload (lz4.c:517-526) */
 #define LA_LZ4B_DEPENDENT 4u	/* frame without the independence bit: matches may reach the previous block (lz4.c:562-591) */
 #define LA_LZ4B_FIRST     8u	/* first block of its frame: dictionary is 64 KiB of zeros (lz4.c:260-261) */
+#define LA_LZ4B_HIST     16u	/* dependent block that continues a frame from the previous batch: its dictionary is
+					 * the la_lz4_batch.hist_len bytes in FRONT of d_dst (d_dst[-hist_len .. 0)) */
 
 typedef struct la_lz4_block {
 	uint64_t src_off;	/* first payload byte inside d_src (after the 4-byte size word) */
@@ -183,7 +186,7 @@ typedef struct la_lz4_batch {
 	uint32_t           *d_frame_status;	/* [n_frames]  LA_ST_* */
 	la_batch_summary   *d_summary;		/* one record */
 	uint32_t            options;		/* LA_LZ4_OPT_* */
-	uint32_t            reserved;
+	uint32_t            hist_len;		/* bytes of carried-over output in front of d_dst (LA_LZ4B_HIST), else 0 */
 	/* XXH32 state of a content checksum that spans batches (one frame at most enters a batch
 	 * and one at most leaves it unfinished): LA_XXH_CARRY_BYTES each, may be NULL when no
 	 * frame has LA_LZ4F_CONT / LA_LZ4F_OPEN.  Must be two different buffers. */

@@ -51,12 +51,13 @@ int  la_lz4_index_build(const uint8_t *img, uint64_t len, int at_eof, la_lz4_ind
 /* A frame of independent blocks may be larger than one window: with a resume record the walker
  * indexes the complete blocks it sees, marks the frame LA_LZ4F_OPEN and continues it at the start
  * of the next window (frame record flagged LA_LZ4F_CONT, no descriptor).  Zero the record before
- * the first window.  Legacy frames continue the same way (their blocks share nothing); frames of
- * dependent blocks are still handed over whole. */
+ * the first window.  Legacy frames continue the same way (their blocks share nothing).  In a frame
+ * of dependent blocks the first block of a continuation is flagged LA_LZ4B_HIST: the caller must
+ * put the tail of the previous window's output in front of the next slab (la_lz4_batch.hist_len). */
 typedef struct la_lz4_resume {
 	uint32_t in_frame;	/* the next window starts inside a frame (1) / a legacy frame (2) */
 	uint32_t bmax;		/* its block maximum */
-	uint32_t flags;		/* bit 0: block checksums, bit 1: content checksum */
+	uint32_t flags;		/* bit 0: block checksums, bit 1: content checksum, bit 2: dependent blocks */
 	uint32_t blocks_so_far;	/* blocks of the frame indexed in earlier windows */
 } la_lz4_resume;
 int  la_lz4_index_build2(const uint8_t *img, uint64_t len, int at_eof, la_lz4_resume *rs, la_lz4_index *idx);

@@ -50,7 +50,7 @@ class _Lz4BatchC(C.Structure):
         ("d_out_len", C.c_void_p), ("d_dst_off", C.c_void_p),
         ("d_block_status", C.c_void_p), ("d_frame_status", C.c_void_p),
         ("d_summary", C.c_void_p),
-        ("options", C.c_uint32), ("reserved", C.c_uint32),
+        ("options", C.c_uint32), ("hist_len", C.c_uint32),
         ("d_carry_in", C.c_void_p), ("d_carry_out", C.c_void_p),   # content hash across batches (NULL here)
     ]
 

@@ -212,6 +212,13 @@ int la_gpu_wait_mark(la_gpu_ctx *c)
 	return LA_OK;
 }
 
+int la_gpu_memcpy_d2d(la_gpu_ctx *c, void *d, const void *src_, uint64_t bytes)
+{
+	if (!c) return LA_ERR_ARG;
+	if (bytes) HIPCHK(c, hipMemcpyAsync(d, src_, bytes, hipMemcpyDeviceToDevice, c->stream));
+	return LA_OK;
+}
+
 int la_gpu_timer_start(la_gpu_ctx *c)
 {
 	if (!c) return LA_ERR_ARG;
@@ -394,7 +401,8 @@ int la_gpu_lz4_decode(la_gpu_ctx *c, const la_lz4_batch *bt)
 	h = prof_open(c, fast ? "lz4_expand_general" : "lz4_expand", sx);
 	la_launch_lz4_expand_general(sx, bt->d_src, bt->src_bytes, bt->d_blocks, n, bt->d_dst,
 	    bt->dst_cap, bt->d_dst_off, bt->d_out_len, bt->d_block_status, w.nseq,
-	    fast ? 0xFFFFFFFEu : 0u);	/* the LDS-window kernel takes every eligible block that got a table */
+	    fast ? 0xFFFFFFFEu : 0u,	/* the LDS-window kernel takes every eligible block that got a table */
+	    bt->hist_len);
 	prof_close(c, h, sx);
 	if (fast) {
 		/* eligible blocks with more sequences than one LDS segment: classified on the device,

@@ -351,7 +351,7 @@ void la_launch_lz4_parse_staged(hipStream_t s, const uint8_t *d_src, uint64_t sr
 void la_launch_lz4_expand_general(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
     const la_lz4_block *d_blocks, uint32_t n, uint8_t *d_dst, uint64_t dst_cap,
     const uint64_t *d_dst_off, const uint32_t *d_out_len, const uint32_t *d_status,
-    const uint32_t *d_nseq, uint32_t fast_max_seq /* 0: take every block */);
+    const uint32_t *d_nseq, uint32_t fast_max_seq /* 0: take every block */, uint32_t hist_len);
 void la_launch_lz4_expand_fast(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
     const la_lz4_block *d_blocks, uint32_t n, uint8_t *d_dst, uint64_t dst_cap,
     const uint64_t *d_dst_off, const uint32_t *d_out_len, uint32_t *d_status,

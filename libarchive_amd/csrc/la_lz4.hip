@@ -352,7 +352,7 @@ __device__ void lz4_expand_block_wave(const uint8_t *s, uint32_t src_len, const 
 __global__ __launch_bounds__(256) void lz4_expand_general_kernel(const uint8_t *__restrict__ src,
     uint64_t src_bytes, const la_lz4_block *__restrict__ blocks, uint32_t n, uint8_t *dst,
     uint64_t dst_cap, const uint64_t *__restrict__ dst_off, const uint32_t *__restrict__ out_len,
-    const uint32_t *__restrict__ status, const uint32_t *__restrict__ nseq, uint32_t fast_max_seq)
+    const uint32_t *__restrict__ status, const uint32_t *__restrict__ nseq, uint32_t fast_max_seq, uint32_t hist_len)
 {
 	int lane = threadIdx.x & 63;
 	uint32_t i = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
@@ -361,10 +361,12 @@ __global__ __launch_bounds__(256) void lz4_expand_general_kernel(const uint8_t *
 	uint32_t fl = blocks[i].flags;
 	/* a dependent block that is not the first of its frame belongs to the
 	 * chain of the wave that owns the frame's first block */
-	if ((fl & LA_LZ4B_DEPENDENT) && !(fl & LA_LZ4B_FIRST))
+	if ((fl & LA_LZ4B_DEPENDENT) && !(fl & (LA_LZ4B_FIRST | LA_LZ4B_HIST)))
 		return;
 	const uint8_t *src_limit = src + src_bytes;
-	uint32_t prev_len = 0;
+	/* a chain that continues a frame from the previous batch starts with that batch's last
+	 * block as its dictionary: the caller has put those bytes in front of the slab */
+	uint32_t prev_len = (fl & LA_LZ4B_HIST) ? hist_len : 0;
 	for (;;) {
 		la_lz4_block b = blocks[i];
 		uint8_t *d = dst + dst_off[i];
@@ -401,7 +403,7 @@ __global__ __launch_bounds__(256) void lz4_expand_general_kernel(const uint8_t *
 		if (i >= n)
 			break;
 		uint32_t nf = blocks[i].flags;
-		if (!(nf & LA_LZ4B_DEPENDENT) || (nf & LA_LZ4B_FIRST))
+		if (!(nf & LA_LZ4B_DEPENDENT) || (nf & (LA_LZ4B_FIRST | LA_LZ4B_HIST)))
 			break;
 		wave_mem_fence();	/* previous block's bytes become the dictionary */
 	}
@@ -410,9 +412,9 @@ __global__ __launch_bounds__(256) void lz4_expand_general_kernel(const uint8_t *
 void la_launch_lz4_expand_general(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
     const la_lz4_block *d_blocks, uint32_t n, uint8_t *d_dst, uint64_t dst_cap,
     const uint64_t *d_dst_off, const uint32_t *d_out_len, const uint32_t *d_status,
-    const uint32_t *d_nseq, uint32_t fast_max_seq)
+    const uint32_t *d_nseq, uint32_t fast_max_seq, uint32_t hist_len)
 {
 	if (n == 0) return;
 	hipLaunchKernelGGL(lz4_expand_general_kernel, dim3((n + 3) / 4), dim3(256), 0, s,
-	    d_src, src_bytes, d_blocks, n, d_dst, dst_cap, d_dst_off, d_out_len, d_status, d_nseq, fast_max_seq);
+	    d_src, src_bytes, d_blocks, n, d_dst, dst_cap, d_dst_off, d_out_len, d_status, d_nseq, fast_max_seq, hist_len);
 }

@@ -32,6 +32,8 @@
 #include <stdio.h>
 
 /* one window in flight: its buffers, its index, what the device said about it */
+#define LA_HIST_BYTES 65536u	/* what a dependent block may reach back into (and the headroom in front of every slab) */
+
 struct lz4_slot {
 	/* compressed window (pinned host memory) */
 	uint8_t *stage;
@@ -60,6 +62,9 @@ struct lz4_private {
 	size_t batch_bytes, max_batch_bytes;
 	la_lz4_resume rs;	/* a frame of independent blocks may span windows: where the walker is */
 	uint8_t *d_carry;	/* 2 x LA_XXH_CARRY_BYTES on the device: content-hash state from window to window */
+	uint8_t *d_hist;	/* 64 KiB on the device: the last block of a window, dictionary of the next one's first
+				 * block when a frame of DEPENDENT blocks spans windows (lz4.c:563-577) */
+	uint32_t hist_len;
 	int carry_flip;		/* which half the next window reads */
 	int upstream_eof;
 	int upstream_fatal;	/* upstream failed while the NEXT window was gathered: reported after this one */
@@ -136,13 +141,14 @@ static int lz4_reader_init(struct archive_read_filter *self)
 		return ARCHIVE_FATAL;
 	}
 	void *cp = NULL;
-	if (la_gpu_malloc(st->gpu, &cp, 2 * LA_XXH_CARRY_BYTES) != LA_OK) {
+	if (la_gpu_malloc(st->gpu, &cp, 2 * LA_XXH_CARRY_BYTES + LA_HIST_BYTES) != LA_OK) {
 		archive_set_error(&self->archive->archive, ARCHIVE_ERRNO_MISC, "Can't allocate lz4 GPU state");
 		la_gpu_close(st->gpu);
 		free(st);
 		return ARCHIVE_FATAL;
 	}
 	st->d_carry = cp;
+	st->d_hist = (uint8_t *)cp + 2 * LA_XXH_CARRY_BYTES;
 	self->data = st;
 	self->vtable = &lz4_reader_vtable;
 	return ARCHIVE_OK;
@@ -287,7 +293,7 @@ static int lz4_launch(struct archive_read_filter *self, struct lz4_private *st, 
 	sl->o_fst = o; o += ALIGN256((size_t)nf * 4);
 	const size_t o_sum = o; o += 256;
 	if (grow_dev(st, &sl->d_src, &sl->d_src_cap, src_len + 64) < 0 ||
-	    grow_dev(st, &sl->d_dst, &sl->d_dst_cap, (size_t)x->max_out + 64) < 0 ||
+	    grow_dev(st, &sl->d_dst, &sl->d_dst_cap, (size_t)x->max_out + 64 + LA_HIST_BYTES) < 0 ||
 	    grow_dev(st, &sl->d_tabs, &sl->d_tabs_cap, o) < 0)
 		return gpu_fail(self, st, "device allocation");
 	if (sl->h_sum == NULL) {
@@ -308,7 +314,13 @@ static int lz4_launch(struct archive_read_filter *self, struct lz4_private *st, 
 	bt.d_src = sl->d_src; bt.src_bytes = src_len;
 	bt.d_blocks = (const la_lz4_block *)(T + o_blocks); bt.n_blocks = nb;
 	bt.d_frames = nf ? (const la_lz4_frame *)(T + o_frames) : NULL; bt.n_frames = nf;
-	bt.d_dst = sl->d_dst; bt.dst_cap = x->max_out;
+	bt.d_dst = (uint8_t *)sl->d_dst + LA_HIST_BYTES; bt.dst_cap = x->max_out;	/* (headroom in front: see d_hist) */
+	if (nb && (x->blocks[0].flags & LA_LZ4B_HIST)) {
+		/* the frame's previous block (at most 64 KiB of it) goes in front of the slab */
+		if (la_gpu_memcpy_d2d(st->gpu, bt.d_dst - st->hist_len, st->d_hist, st->hist_len) != LA_OK)
+			return gpu_fail(self, st, "history copy");
+		bt.hist_len = st->hist_len;
+	}
 	bt.d_out_len = (uint32_t *)(T + sl->o_outlen);
 	bt.d_dst_off = (uint64_t *)(T + sl->o_dstoff);
 	bt.d_block_status = (uint32_t *)(T + sl->o_bst);
@@ -402,10 +414,23 @@ static ssize_t lz4_resolve(struct archive_read_filter *self, struct lz4_private 
 		lz4_apply_end_kind(st, x->end_kind);
 	}
 
+	if (nf && nb && (x->frames[nf - 1].flags & LA_LZ4F_OPEN) && (x->blocks[nb - 1].flags & LA_LZ4B_DEPENDENT) &&
+	    x->frames[nf - 1].n_blocks != 0 && !st->pending_fatal && !st->eof) {
+		/* the open frame's blocks depend on each other: keep its last block (<= 64 KiB of it)
+		 * for the first block of the next window */
+		uint32_t last_len = 0;
+		if (la_gpu_memcpy_d2h(st->gpu, &last_len, T + sl->o_outlen + (size_t)(nb - 1) * 4, 4) != LA_OK ||
+		    la_gpu_sync(st->gpu) != LA_OK)
+			return gpu_fail(self, st, "status copy");
+		st->hist_len = last_len < LA_HIST_BYTES ? last_len : LA_HIST_BYTES;
+		if (la_gpu_memcpy_d2d(st->gpu, st->d_hist, (uint8_t *)sl->d_dst + LA_HIST_BYTES + sm.total_out - st->hist_len,
+		    st->hist_len) != LA_OK)
+			return gpu_fail(self, st, "history copy");
+	}
 	if (delivered) {
 		if (grow_pinned(st, &sl->slab, &sl->slab_cap, (size_t)delivered, 0) < 0)
 			return gpu_fail(self, st, "pinned slab allocation");
-		if (la_gpu_memcpy_d2h(st->gpu, sl->slab, sl->d_dst, (size_t)delivered) != LA_OK ||
+		if (la_gpu_memcpy_d2h(st->gpu, sl->slab, (uint8_t *)sl->d_dst + LA_HIST_BYTES, (size_t)delivered) != LA_OK ||
 		    la_gpu_mark(st->gpu) != LA_OK)
 			return gpu_fail(self, st, "device to host copy");
 	}

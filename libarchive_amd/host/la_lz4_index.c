@@ -114,7 +114,7 @@ int la_lz4_index_build2(const uint8_t *img, uint64_t len, int at_eof, la_lz4_res
 				/* continuation of a frame that began in an earlier window */
 				p = pos;
 				bmax = rs->bmax;
-				indep = 1;
+				indep = !(rs->flags & 4u);
 				bsum = (rs->flags & 1u) ? 4 : 0;
 				ssum = (rs->flags & 2u) != 0;
 				blocks_before = rs->blocks_so_far;
@@ -180,20 +180,20 @@ int la_lz4_index_build2(const uint8_t *img, uint64_t len, int at_eof, la_lz4_res
 				b->dst_cap = bmax;
 				b->flags = ((w & 0x80000000u) && csize ? LA_LZ4B_STORED : 0) |
 				    (bsum ? LA_LZ4B_CHECKSUM : 0) | (indep ? 0 : LA_LZ4B_DEPENDENT) |
-				    (x->n_blocks - 1 == x->frames[fi].first_block ? LA_LZ4B_FIRST : 0);
+				    (x->n_blocks - 1 == x->frames[fi].first_block ? (cont ? (indep ? 0 : LA_LZ4B_HIST) : LA_LZ4B_FIRST) : 0);
 				b->block_sum = bsum ? le32(img + p + 4 + csize) : 0;
 				x->max_out += bmax;
 				p += 4ull + csize + bsum;
 				x->frames[fi].n_blocks++;
 			}
 			if (end >= 0) {
-				if (!at_eof && rs && indep) {
+				if (!at_eof && rs) {
 					/* the frame goes on in the next window: its complete blocks are decoded
 					 * now, the content hash is carried over */
 					x->frames[fi].flags = (x->frames[fi].flags & ~LA_LZ4F_CONTENT_SUM) | LA_LZ4F_OPEN;
 					rs->in_frame = 1;
 					rs->bmax = bmax;
-					rs->flags = (bsum ? 1u : 0u) | (ssum ? 2u : 0u);
+					rs->flags = (bsum ? 1u : 0u) | (ssum ? 2u : 0u) | (indep ? 0u : 4u);
 					rs->blocks_so_far = blocks_before + x->frames[fi].n_blocks;
 					x->end_kind = LA_END_NEED_MORE;
 					x->consumed = p;

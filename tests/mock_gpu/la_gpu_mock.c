@@ -12,6 +12,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* test hook: how many blocks were decoded against a carried history */
+static unsigned long mock_hist_blocks;
+unsigned long la_gpu_mock_hist_blocks(void) { return mock_hist_blocks; }
+
 struct la_gpu_ctx { char err[64]; };
 _Static_assert(sizeof(orc_xxh32_state) <= LA_XXH_CARRY_BYTES, "carry buffer too small for the oracle's state");
 
@@ -36,6 +40,7 @@ int la_gpu_malloc_host(la_gpu_ctx *c, void **p, uint64_t n) { return la_gpu_mall
 int la_gpu_free_host(la_gpu_ctx *c, void *p) { return la_gpu_free(c, p); }
 int la_gpu_memcpy_h2d(la_gpu_ctx *c, void *d, const void *h, uint64_t n) { (void)c; if (n) memcpy(d, h, n); return LA_OK; }
 int la_gpu_memcpy_d2h(la_gpu_ctx *c, void *h, const void *d, uint64_t n) { (void)c; if (n) memcpy(h, d, n); return LA_OK; }
+int la_gpu_memcpy_d2d(la_gpu_ctx *c, void *d, const void *s, uint64_t n) { (void)c; if (n) memmove(d, s, n); return LA_OK; }
 
 static void summary_init(la_batch_summary *sm)
 {
@@ -69,6 +74,10 @@ int la_gpu_lz4_decode(la_gpu_ctx *c, const la_lz4_batch *bt)
 			int dl = 0;
 			if (b->flags & LA_LZ4B_DEPENDENT) {
 				/* lz4.c:563-577: the previous block (at most 64 KiB), zero padded in front */
+				if (b->flags & LA_LZ4B_HIST) {
+					mock_hist_blocks++;
+					prev_len = bt->hist_len;	/* the previous batch's last block sits in front of d_dst */
+				}
 				const uint32_t keep = (b->flags & LA_LZ4B_FIRST) ? 0 : (prev_len < 65536u ? prev_len : 65536u);
 				memset(dict, 0, 65536 - keep);
 				if (keep)

@@ -192,6 +192,63 @@ def test_lz4_legacy_frame_across_windows(gpu_ctx, monkeypatch):
             assert got[0] == plain + tplain.tobytes()
 
 
+def _dependent_frame(data, block=65536, flg=0x44):
+    """A frame of DEPENDENT blocks made by liblz4's streaming compressor (every block may
+    reference the 64 KiB before it)."""
+    import ctypes as C
+    import streams as S
+    l = C.CDLL("liblz4.so.1")
+    l.LZ4_createStream.restype = C.c_void_p
+    l.LZ4_compress_fast_continue.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    l.LZ4_freeStream.argtypes = [C.c_void_p]
+    src = C.create_string_buffer(data, len(data))
+    base = C.addressof(src)
+    st = l.LZ4_createStream()
+    out = C.create_string_buffer(block + block // 255 + 64)
+    blocks = []
+    for o in range(0, len(data), block):
+        n = min(block, len(data) - o)
+        k = l.LZ4_compress_fast_continue(st, base + o, out, n, len(out), 1)
+        assert k > 0
+        blocks.append((data[o:o + n], S.lz4_block(out.raw[:k], bsum=bool(flg & 0x10))))
+    l.LZ4_freeStream(st)
+    return S.lz4_frame(blocks, flg=flg)
+
+
+def test_lz4_dependent_frame_across_windows(gpu_ctx, monkeypatch):
+    """A frame of dependent blocks several windows long: the last block of each window is the
+    dictionary of the next window's first block (carried on the device), the content hash travels
+    as state.  Clean, damaged, cut."""
+    import random
+    import oracle_lib as O
+    import streams as S
+    monkeypatch.setenv("LA_GPU_BATCH_MIB", "1")
+    rnd = random.Random(91)
+    words = [rnd.randbytes(rnd.randint(2, 11)) for _ in range(3000)]
+    data = b"".join(rnd.choice(words) for _ in range(1600000))[:9 << 20]
+    for flg in (0x44, 0x54, 0x40):
+        img, plain = _dependent_frame(data, flg=flg)
+        assert plain == data and len(img) > 3 << 20
+        tail, tplain = S.synth_lz4_stream(2, 0, 2, blocks_per_frame=2, block_size=3000, nthreads=1)
+        whole = img + tail.tobytes()
+        for variant in range(4):
+            m = bytearray(whole)
+            if variant == 1:
+                m[len(img) // 2] ^= 0x10
+            elif variant == 2:
+                m = m[:len(img) * 3 // 4]
+            elif variant == 3:
+                m[len(img) - 2] ^= 0x02
+            m = bytes(m)
+            out, res = O.lz4_stream_decode(m, 1 << 27)
+            want = (out.tobytes(), res.rc, res.errmsg.decode())
+            r = la_api.cat(m, read_size=rnd.choice([None, 65536]))
+            got = la_api.as_reference_tuple(r)
+            assert got == want, (hex(flg), variant, len(got[0]), len(want[0]), got[1:], want[1:])
+            if variant == 0:
+                assert len(r.block_sizes) >= 3
+
+
 def test_lz4_file_reader(gpu_ctx, tmp_path):
     img, plain = S.synth_lz4_stream(8, 0, 6, blocks_per_frame=4, block_size=65536, nthreads=2)
     f = tmp_path / "x.lz4"

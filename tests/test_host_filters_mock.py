@@ -37,6 +37,7 @@ from test_gpu_filters import (  # noqa: E402,F401
     test_lz4_frame_larger_than_the_window,
     test_lz4_window_grows_for_large_blocks,
     test_lz4_legacy_frame_across_windows,
+    test_lz4_dependent_frame_across_windows,
     test_lz4_file_reader,
     test_gzip_behaviour_table_through_the_api,
     test_gzip_metadata_snapshot,
@@ -118,3 +119,14 @@ def test_gzip_window_fuzz(gpu_ctx, monkeypatch):
         for rs in (None, 4096):
             got = la_api.as_reference_tuple(la_api.cat(m, read_size=rs))
             assert got == want, (t, how, rs, len(got[0]), len(want[0]), got[1:], want[1:])
+
+
+
+def test_dependent_frame_really_used_the_carried_history(gpu_ctx, monkeypatch):
+    """The imported dependent-frame test passes trivially if the filter widened its window to hold
+    the whole frame; the mock counts the blocks it decoded against a carried history."""
+    lib = C.CDLL(os.path.join(MOCK_DIR, "libla_host_mock.so"))
+    lib.la_gpu_mock_hist_blocks.restype = C.c_ulong
+    before = lib.la_gpu_mock_hist_blocks()
+    test_lz4_dependent_frame_across_windows(gpu_ctx, monkeypatch)
+    assert lib.la_gpu_mock_hist_blocks() - before >= 3 * 4 * 5
