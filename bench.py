@@ -150,13 +150,13 @@ def main_gzip(args):
     plan = GzDevicePlan(ctx, d_src, tiled)
     C_bytes, U_bytes = int(d_src.numel()), int(tiled.max_out)
     for _ in range(args.warmup):
-        plan.run()
+        plan.run(args.extra_options)
     torch.cuda.synchronize()
     ctx.profile_enable(True)
     phase_ms = {}
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        plan.run()
+        plan.run(args.extra_options)
         for name, ms in ctx.profile_read():
             phase_ms.setdefault(name, []).append(ms)
     torch.cuda.synchronize()

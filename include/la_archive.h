@@ -35,6 +35,8 @@ extern "C" {
 
 #define ARCHIVE_FORMAT_RAW   0x90000	/* archive.h */
 #define ARCHIVE_FORMAT_EMPTY 0x60000
+#define ARCHIVE_FORMAT_TAR        0x30000	/* archive.h:353-357 */
+#define ARCHIVE_FORMAT_TAR_USTAR  (ARCHIVE_FORMAT_TAR | 1)
 
 struct archive;
 struct archive_entry;
@@ -51,6 +53,8 @@ int  archive_read_support_filter_lz4(struct archive *);				/* archive.h:469 */
 int  archive_read_support_filter_none(struct archive *);
 int  archive_read_support_format_raw(struct archive *);
 int  archive_read_support_format_empty(struct archive *);
+int  archive_read_support_format_tar(struct archive *);			/* ustar / old tar only, la_format_tar.c */
+int  archive_read_support_format_all(struct archive *);			/* the formats of this slice: tar + empty */
 
 int  archive_read_open(struct archive *, void *client_data, archive_open_callback *,
 	archive_read_callback *, archive_close_callback *);
@@ -61,6 +65,7 @@ int  archive_read_open_filename(struct archive *, const char *filename, size_t b
 int  archive_read_next_header(struct archive *, struct archive_entry **);	/* archive_read.c:607-669 */
 int  archive_read_data_block(struct archive *, const void **buff, size_t *size, int64_t *offset);	/* archive_read.c:966-982 */
 ssize_t archive_read_data(struct archive *, void *, size_t);			/* archive_read.c:814-893 */
+int  archive_read_data_skip(struct archive *);					/* archive_read.c:913-939 */
 int  archive_read_data_into_fd(struct archive *, int fd);			/* archive_read_data_into_fd.c */
 int  archive_read_close(struct archive *);
 int  archive_read_free(struct archive *);
@@ -81,6 +86,10 @@ const char *archive_format_name(struct archive *);
 const char *archive_entry_pathname(struct archive_entry *);
 int64_t     archive_entry_mtime(struct archive_entry *);
 int         archive_entry_mtime_is_set(struct archive_entry *);
+int64_t     archive_entry_size(struct archive_entry *);
+int         archive_entry_size_is_set(struct archive_entry *);
+unsigned    archive_entry_filetype(struct archive_entry *);			/* AE_IFREG 0100000, AE_IFDIR 0040000 ... */
+unsigned    archive_entry_perm(struct archive_entry *);
 void        archive_entry_set_pathname(struct archive_entry *, const char *);
 void        archive_entry_set_mtime(struct archive_entry *, int64_t, long);
 

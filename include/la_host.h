@@ -95,6 +95,13 @@ int    la_gz_index_build(const uint8_t *img, uint64_t len, int at_eof, la_gz_ind
  * first_cap: minimum output slot of the first member (its ISIZE claim proved too small) */
 int    la_gz_index_build2(const uint8_t *img, uint64_t len, int at_eof, uint32_t first_skip,
            uint32_t first_cap, la_gz_index *idx);
+/* flags: LA_GZ_INDEX_STRICT = a speculative boundary must also carry the XFL / OS bytes real writers emit
+ * (XFL 0, 2 or 4; OS 0..13 or 255) -- a few thousand times fewer false boundaries inside deflate data.  A stream
+ * whose headers do not look like that is still read correctly: the decode of the member in front ends early, the
+ * filter sees a header there and goes on without the flag (la_filter_gzip.c). */
+#define LA_GZ_INDEX_STRICT 1u
+int    la_gz_index_build3(const uint8_t *img, uint64_t len, int at_eof, uint32_t first_skip,
+           uint32_t first_cap, uint32_t flags, la_gz_index *idx);
 void   la_gz_index_free(la_gz_index *idx);
 
 /* The reference's error string for a device status word / an end kind */

@@ -28,6 +28,15 @@
 #include "../../include/la_host.h"
 #include <errno.h>
 #include <stdio.h>
+#include <time.h>
+
+/* LA_GPU_TRACE=1: per-window phase times on stderr (diagnostic) */
+static double gz_now(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
 
 #define OUT_BLOCK 65536u	/* gzip.c:314 */
 
@@ -47,6 +56,8 @@ struct gzip_private {
 	uint64_t total_out;	/* bytes decoded so far (delivered + carry) */
 	uint32_t hint_skip, hint_cap;
 	int strict;
+	int trace;
+	int loose;		/* the stream's headers carry unusual XFL / OS bytes: index without LA_GZ_INDEX_STRICT */
 	/* header metadata (gzip.c:280-296) */
 	uint32_t mtime;
 	char *name;
@@ -130,6 +141,7 @@ static int gzip_bidder_init(struct archive_read_filter *self)
 	const char *dev = getenv("LA_GPU_DEVICE"), *bm = getenv("LA_GPU_BATCH_MIB"), *sv = getenv("LA_GZIP_STRICT");
 	st->batch_bytes = (size_t)(bm && atoi(bm) > 0 ? atoi(bm) : 256) << 20;
 	st->strict = sv && atoi(sv) != 0;
+	st->trace = getenv("LA_GPU_TRACE") != NULL && atoi(getenv("LA_GPU_TRACE")) != 0;
 	int rc = la_gpu_open(dev ? atoi(dev) : 0, &st->gpu);
 	if (rc != LA_OK) {
 		archive_set_error(&self->archive->archive, ARCHIVE_ERRNO_MISC,
@@ -219,6 +231,7 @@ static int gzip_run_batch(struct archive_read_filter *self, struct gzip_private 
 	    gz_grow_dev(st, &st->d_tabs, &st->d_tabs_cap, o) < 0)
 		return gz_gpu_fail(self, st, "device allocation");
 	uint8_t *T = st->d_tabs;
+	const double b0 = st->trace ? gz_now() : 0;
 	if (la_gpu_memcpy_h2d(st->gpu, st->d_src, st->stage, src_len) != LA_OK ||
 	    la_gpu_memcpy_h2d(st->gpu, T + o_mem, x->members, (size_t)n * sizeof(la_gz_member)) != LA_OK)
 		return gz_gpu_fail(self, st, "host to device copy");
@@ -243,6 +256,7 @@ static int gzip_run_batch(struct archive_read_filter *self, struct gzip_private 
 	if (la_gpu_memcpy_d2h(st->gpu, st->h_res, T + o_res, (size_t)n * sizeof(la_gz_result)) != LA_OK ||
 	    la_gpu_sync(st->gpu) != LA_OK)
 		return gz_gpu_fail(self, st, "result copy");
+	const double b1 = st->trace ? gz_now() : 0;
 
 	/* ---- stream-order walk ---- */
 	uint64_t total = st->total_out;		/* stream offset of the next decoded byte */
@@ -309,6 +323,17 @@ static int gzip_run_batch(struct archive_read_filter *self, struct gzip_private 
 			take = i + 1;
 			total += r->out_len;
 			if (x->speculative && !h->bgzf_size && (uint64_t)r->consumed + 8 < m->src_len) {
+				const uint64_t p = m->src_off + (uint64_t)r->consumed + 8;
+				const uint8_t *q = st->stage + p;
+				const uint64_t rem = st->stage_len - p;
+				if (!st->loose && rem >= 4 && q[0] == 0x1f && q[1] == 0x8b && q[2] == 0x08 && (q[3] & 0xE0) == 0) {
+					/* a header the strict boundary search passed over (unusual XFL / OS): the
+					 * stream goes on here; from now on every 1f 8b 08 is a candidate */
+					st->loose = 1;
+					*used = (size_t)p;
+					stop = 1;
+					break;
+				}
 				/* bytes after the trailer are not a member header: silent end (gzip.c:351-353) */
 				st->eof = 1;
 				stop = 1;
@@ -359,6 +384,7 @@ static int gzip_run_batch(struct archive_read_filter *self, struct gzip_private 
 	if (gz_grow_pinned(st, &st->slab, &st->slab_cap, st->carry_len + (size_t)new_bytes + 16, st->carry_len) < 0)
 		return gz_gpu_fail(self, st, "pinned slab allocation");
 	uint8_t *dstp = st->slab + st->carry_len;
+	const double b2 = st->trace ? gz_now() : 0;
 	if (take) {
 		if (contiguous && last_out == 0) {
 			if (la_gpu_memcpy_d2h(st->gpu, dstp, st->d_dst, (size_t)new_bytes) != LA_OK)
@@ -375,6 +401,9 @@ static int gzip_run_batch(struct archive_read_filter *self, struct gzip_private 
 		if (la_gpu_sync(st->gpu) != LA_OK)
 			return gz_gpu_fail(self, st, "device to host copy");
 	}
+	if (st->trace)
+		fprintf(stderr, "la_gzip:   h2d+decode %.1f ms, walk+grow %.1f ms, d2h %.1f ms (%llu bytes, contiguous %d)\n",
+		    b1 - b0, b2 - b1, gz_now() - b2, (unsigned long long)new_bytes, contiguous);
 	st->total_out = total + last_out;
 	st->carry_len += (size_t)new_bytes;
 
@@ -418,6 +447,7 @@ static ssize_t gzip_filter_read(struct archive_read_filter *self, const void **p
 			}
 			return 0;
 		}
+		const double t0 = st->trace ? gz_now() : 0;
 		while (!st->upstream_eof && st->stage_len < st->batch_bytes) {
 			ssize_t avail;
 			const void *up = __archive_read_filter_ahead(self->upstream, 1, &avail);
@@ -436,8 +466,10 @@ static ssize_t gzip_filter_read(struct archive_read_filter *self, const void **p
 			st->stage_len += n;
 			__archive_read_filter_consume(self->upstream, (int64_t)n);
 		}
+		const double t1 = st->trace ? gz_now() : 0;
 		la_gz_index idx;
-		if (la_gz_index_build2(st->stage, st->stage_len, st->upstream_eof, st->hint_skip, st->hint_cap, &idx) != 0) {
+		if (la_gz_index_build3(st->stage, st->stage_len, st->upstream_eof, st->hint_skip, st->hint_cap,
+		    st->loose ? 0 : LA_GZ_INDEX_STRICT, &idx) != 0) {
 			archive_set_error(&self->archive->archive, ENOMEM, "Can't allocate data for gzip decompression");
 			return ARCHIVE_FATAL;
 		}
@@ -446,6 +478,12 @@ static ssize_t gzip_filter_read(struct archive_read_filter *self, const void **p
 			la_gz_index_free(&idx);
 			if (kind == LA_END_NEED_MORE) {
 				if (st->upstream_eof) { st->eof = 1; continue; }
+				if (!st->loose) {
+					/* no trusted boundary in the whole window: before widening it, look
+					 * with every 1f 8b 08 as a candidate (and keep doing so) */
+					st->loose = 1;
+					continue;
+				}
 				st->batch_bytes *= 2;	/* one member larger than the window */
 				continue;
 			}
@@ -456,8 +494,12 @@ static ssize_t gzip_filter_read(struct archive_read_filter *self, const void **p
 			continue;
 		}
 		size_t used = 0;
+		const double t2 = st->trace ? gz_now() : 0;
 		int rc = gzip_run_batch(self, st, &idx, &used);
 		int made_progress = used > 0;
+		if (st->trace)
+			fprintf(stderr, "la_gzip: window %zu bytes, %u members: gather %.1f ms, index %.1f ms, batch %.1f ms, used %zu, out %zu\n",
+			    st->stage_len, idx.n, t1 - t0, t2 - t1, gz_now() - t2, used, st->last_ret);
 		la_gz_index_free(&idx);
 		if (rc < 0)
 			return rc;

@@ -105,7 +105,7 @@ static int push(la_gz_index *x)
 }
 
 /* next offset >= from where a plausible member header starts, or len */
-static uint64_t next_candidate(const uint8_t *img, uint64_t len, uint64_t from)
+static uint64_t next_candidate(const uint8_t *img, uint64_t len, uint64_t from, int strict)
 {
 	static const uint8_t magic[3] = { 0x1f, 0x8b, 0x08 };
 	while (from + 4 <= len) {
@@ -113,8 +113,13 @@ static uint64_t next_candidate(const uint8_t *img, uint64_t len, uint64_t from)
 		if (!hit)
 			return len;
 		uint64_t o = (uint64_t)(hit - img);
-		if (o + 4 <= len && (img[o + 3] & 0xE0) == 0)
-			return o;
+		if (o + 4 <= len && (img[o + 3] & 0xE0) == 0) {
+			/* XFL (byte 8) and OS (byte 9) as gzip, zlib, pigz, bgzip, Java and Go write them; a header cut
+			 * by the window edge passes (the walker then asks for more input) */
+			if (!strict || o + 10 > len ||
+			    ((img[o + 8] == 0 || img[o + 8] == 2 || img[o + 8] == 4) && (img[o + 9] <= 13 || img[o + 9] == 255)))
+				return o;
+		}
 		from = o + 1;
 	}
 	return len;
@@ -123,6 +128,13 @@ static uint64_t next_candidate(const uint8_t *img, uint64_t len, uint64_t from)
 int la_gz_index_build2(const uint8_t *img, uint64_t len, int at_eof, uint32_t first_skip,
     uint32_t first_cap, la_gz_index *x)
 {
+	return la_gz_index_build3(img, len, at_eof, first_skip, first_cap, 0, x);
+}
+
+int la_gz_index_build3(const uint8_t *img, uint64_t len, int at_eof, uint32_t first_skip,
+    uint32_t first_cap, uint32_t flags, la_gz_index *x)
+{
+	const int strict = (flags & LA_GZ_INDEX_STRICT) != 0;
 	uint64_t pos = 0, out = 0;
 	memset(x, 0, sizeof(*x));
 	x->end_kind = LA_END_EOF;
@@ -163,10 +175,10 @@ int la_gz_index_build2(const uint8_t *img, uint64_t len, int at_eof, uint32_t fi
 				next = len;	/* truncated member: the decode reports it */
 			}
 		} else {
-			next = next_candidate(img, len, body + 2);
+			next = next_candidate(img, len, body + 2, strict);
 			/* boundaries the decode already refuted for this member are skipped */
 			for (uint32_t k = 0; x->n == 0 && k < first_skip && next < len; k++)
-				next = next_candidate(img, len, next + 1);
+				next = next_candidate(img, len, next + 1, strict);
 			x->speculative = 1;
 			if (next == len && !at_eof) {
 				/* cannot tell whether this member is complete: wait for more input

@@ -58,6 +58,10 @@ int archive_errno(struct archive *a) { return a->archive_error_number; }
 const char *archive_entry_pathname(struct archive_entry *e) { return e->pathname; }
 int64_t archive_entry_mtime(struct archive_entry *e) { return e->mtime; }
 int archive_entry_mtime_is_set(struct archive_entry *e) { return e->mtime_set; }
+int64_t archive_entry_size(struct archive_entry *e) { return e->size; }
+int archive_entry_size_is_set(struct archive_entry *e) { return e->size_set; }
+unsigned archive_entry_filetype(struct archive_entry *e) { return e->filetype; }
+unsigned archive_entry_perm(struct archive_entry *e) { return e->mode; }
 void archive_entry_set_pathname(struct archive_entry *e, const char *p)
 {
 	snprintf(e->pathname, sizeof(e->pathname), "%s", p ? p : "");
@@ -475,7 +479,7 @@ static int empty_read_data(struct archive_read *a, const void **b, size_t *s, in
 	return ARCHIVE_EOF;
 }
 
-static int register_format(struct archive_read *a, struct archive_format_descriptor d)
+int __archive_read_register_format(struct archive_read *a, struct archive_format_descriptor d)
 {
 	for (int i = 0; i < 4; i++) {
 		if (a->formats[i].bid == d.bid)
@@ -496,16 +500,24 @@ int archive_read_support_format_raw(struct archive *_a)
 		archive_set_error(_a, ENOMEM, "Can't allocate raw_info data");
 		return ARCHIVE_FATAL;
 	}
-	struct archive_format_descriptor d = { info, "raw", raw_bid, raw_read_header, raw_read_data, raw_cleanup };
+	struct archive_format_descriptor d = { info, "raw", raw_bid, raw_read_header, raw_read_data, raw_cleanup, NULL };
 	for (int i = 0; i < 4; i++)
 		if (a->formats[i].bid == raw_bid) { free(info); return ARCHIVE_OK; }
-	return register_format(a, d);
+	return __archive_read_register_format(a, d);
 }
 
 int archive_read_support_format_empty(struct archive *_a)
 {
-	struct archive_format_descriptor d = { NULL, "empty", empty_bid, empty_read_header, empty_read_data, NULL };
-	return register_format((struct archive_read *)_a, d);
+	struct archive_format_descriptor d = { NULL, "empty", empty_bid, empty_read_header, empty_read_data, NULL, NULL };
+	return __archive_read_register_format((struct archive_read *)_a, d);
+}
+
+int archive_read_support_format_all(struct archive *_a)
+{
+	int r = archive_read_support_format_tar(_a);
+	if (r != ARCHIVE_OK)
+		return r;
+	return archive_read_support_format_empty(_a);
 }
 
 static int choose_format(struct archive_read *a)
@@ -725,6 +737,17 @@ int archive_read_next_header(struct archive *_a, struct archive_entry **entryp)
 		return ARCHIVE_EOF;
 	memset(&a->entry, 0, sizeof(a->entry));
 	archive_clear_error(_a);
+	/* archive_read.c:621-635: whatever the client left of the previous entry is skipped first */
+	int r1 = ARCHIVE_OK;
+	if (a->archive.state == LA_STATE_DATA) {
+		r1 = archive_read_data_skip(_a);
+		if (r1 == ARCHIVE_EOF)
+			archive_set_error(_a, EIO, "Premature end-of-file.");
+		if (r1 == ARCHIVE_EOF || r1 == ARCHIVE_FATAL) {
+			a->archive.state = LA_STATE_FATAL;
+			return ARCHIVE_FATAL;
+		}
+	}
 	int r = a->format->read_header(a, &a->entry);
 	switch (r) {
 	case ARCHIVE_EOF:
@@ -743,6 +766,31 @@ int archive_read_next_header(struct archive *_a, struct archive_entry **entryp)
 	a->read_data_output_offset = 0;
 	a->read_data_remaining = 0;
 	*entryp = &a->entry;
+	return (r < r1 || r == ARCHIVE_EOF) ? r : r1;
+}
+
+/* archive_read.c:913-939 */
+int archive_read_data_skip(struct archive *_a)
+{
+	struct archive_read *a = (struct archive_read *)_a;
+	int r;
+	if (a->archive.state != LA_STATE_DATA) {
+		archive_set_error(_a, ARCHIVE_ERRNO_MISC, "archive_read_data_skip: archive in wrong state");
+		return ARCHIVE_FATAL;
+	}
+	if (a->format->read_data_skip != NULL)
+		r = (a->format->read_data_skip)(a);
+	else {
+		const void *buff;
+		size_t size;
+		int64_t offset;
+		while ((r = archive_read_data_block(_a, &buff, &size, &offset)) == ARCHIVE_OK)
+			;
+	}
+	if (r == ARCHIVE_EOF)
+		r = ARCHIVE_OK;
+	if (a->archive.state != LA_STATE_FATAL)
+		a->archive.state = LA_STATE_HEADER;
 	return r;
 }
 

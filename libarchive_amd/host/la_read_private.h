@@ -102,7 +102,20 @@ struct archive_entry {
 	char    pathname[1024];
 	int64_t mtime;
 	int     mtime_set;
+	int64_t size;			/* set by the tar walker */
+	int     size_set;
+	unsigned filetype;		/* AE_IF* */
+	unsigned mode;			/* permission bits */
 };
+
+/* archive_entry.h:183-189 */
+#define AE_IFMT   0170000u
+#define AE_IFREG  0100000u
+#define AE_IFLNK  0120000u
+#define AE_IFCHR  0020000u
+#define AE_IFBLK  0060000u
+#define AE_IFDIR  0040000u
+#define AE_IFIFO  0010000u
 
 struct archive_read_client {
 	archive_open_callback  *opener;
@@ -118,6 +131,7 @@ struct archive_format_descriptor {
 	int (*read_header)(struct archive_read *, struct archive_entry *);
 	int (*read_data)(struct archive_read *, const void **, size_t *, int64_t *);
 	int (*cleanup)(struct archive_read *);
+	int (*read_data_skip)(struct archive_read *);	/* optional (archive_read.c:925-932) */
 };
 
 struct archive_read {
@@ -137,6 +151,7 @@ struct archive_read {
 /* archive_read_private.h:242-253 */
 int __archive_read_register_bidder(struct archive_read *a, void *bidder_data, const char *name,
 	const struct archive_read_filter_bidder_vtable *vtable);
+int __archive_read_register_format(struct archive_read *a, struct archive_format_descriptor d);
 const void *__archive_read_ahead(struct archive_read *, size_t, ssize_t *);
 const void *__archive_read_filter_ahead(struct archive_read_filter *, size_t, ssize_t *);
 int64_t __archive_read_consume(struct archive_read *, int64_t);

@@ -24,7 +24,8 @@ def _lib():
     lib.archive_read_new.restype = C.c_void_p
     for f in ("archive_read_support_filter_all", "archive_read_support_filter_gzip", "archive_read_support_filter_lz4",
               "archive_read_support_format_raw", "archive_read_support_format_empty", "archive_read_close",
-              "archive_read_free", "archive_filter_count", "archive_errno", "archive_format"):
+              "archive_read_free", "archive_filter_count", "archive_errno", "archive_format",
+              "archive_read_support_format_tar", "archive_read_support_format_all", "archive_read_data_skip"):
         getattr(lib, f).argtypes = [C.c_void_p]
         getattr(lib, f).restype = C.c_int
     lib.archive_read_open_memory2.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]
@@ -47,6 +48,12 @@ def _lib():
     lib.archive_entry_mtime.argtypes = [C.c_void_p]
     lib.archive_entry_mtime.restype = C.c_int64
     lib.archive_entry_mtime_is_set.argtypes = [C.c_void_p]
+    lib.archive_entry_size.argtypes = [C.c_void_p]
+    lib.archive_entry_size.restype = C.c_int64
+    lib.archive_entry_filetype.argtypes = [C.c_void_p]
+    lib.archive_entry_filetype.restype = C.c_uint
+    lib.archive_entry_perm.argtypes = [C.c_void_p]
+    lib.archive_entry_perm.restype = C.c_uint
     lib._la_api_ready = True
     return lib
 
@@ -129,3 +136,72 @@ def as_reference_tuple(res):
     if res.rc in (ARCHIVE_EOF, ARCHIVE_OK):
         return res.data, 0, ""
     return res.data, ARCHIVE_FATAL, res.error or ""
+
+
+class ListResult:
+    def __init__(self):
+        self.open_rc = None
+        self.entries = []       # [(pathname, size, filetype, perm, mtime, data or None)]
+        self.rc = None          # what ended the header loop (ARCHIVE_EOF on a clean end)
+        self.error = None
+        self.filters = []
+        self.format = None
+        self.format_name = None
+
+
+def list_entries(image, read_size=None, filename=None, block_size=10240, read_bodies=True, skip_every=0):
+    """bsdtar -t / -x shape: support_filter_all + support_format_all, then the
+    archive_read_next_header / archive_read_data_block loop (tar/read.c:206-400).  With
+    `skip_every` = k every k-th body is left unread so that next_header has to skip it."""
+    lib = _lib()
+    a = lib.archive_read_new()
+    res = ListResult()
+    try:
+        lib.archive_read_support_filter_all(a)
+        lib.archive_read_support_format_all(a)
+        if filename is not None:
+            res.open_rc = lib.archive_read_open_filename(a, filename.encode(), block_size)
+        else:
+            buf = C.create_string_buffer(bytes(image), len(image))
+            res._keep = buf
+            res.open_rc = lib.archive_read_open_memory2(a, buf, len(image), read_size or max(len(image), 1))
+        if res.open_rc != ARCHIVE_OK:
+            e = lib.archive_error_string(a)
+            res.error = e.decode() if e else None
+            res.rc = res.open_rc
+            return res
+        n = lib.archive_filter_count(a)
+        res.filters = [(lib.archive_filter_code(a, i), lib.archive_filter_name(a, i).decode()) for i in range(n)]
+        ent = C.c_void_p()
+        p, sz, off = C.c_void_p(), C.c_size_t(), C.c_int64()
+        i = 0
+        while True:
+            r = lib.archive_read_next_header(a, C.byref(ent))
+            if r != ARCHIVE_OK:
+                break
+            i += 1
+            meta = (lib.archive_entry_pathname(ent).decode("latin-1"), lib.archive_entry_size(ent),
+                    lib.archive_entry_filetype(ent), lib.archive_entry_perm(ent), lib.archive_entry_mtime(ent))
+            body = None
+            if read_bodies and not (skip_every and i % skip_every == 0):
+                out = bytearray()
+                while True:
+                    r = lib.archive_read_data_block(a, C.byref(p), C.byref(sz), C.byref(off))
+                    if r != ARCHIVE_OK:
+                        break
+                    assert off.value == len(out)
+                    out += C.string_at(p.value, sz.value)
+                body = bytes(out)
+                if r != ARCHIVE_EOF:
+                    res.entries.append(meta + (body,))
+                    break
+            res.entries.append(meta + (body,))
+        res.rc = r
+        e = lib.archive_error_string(a)
+        res.error = e.decode() if e else None
+        res.format = lib.archive_format(a)
+        fn = lib.archive_format_name(a)
+        res.format_name = fn.decode() if fn else None
+        return res
+    finally:
+        lib.archive_read_free(a)

@@ -323,3 +323,31 @@ def test_gzip_mutated_streams(gpu_ctx):
         if r.filters and r.filters[0][1] != "gzip":
             continue
         assert la_api.as_reference_tuple(r) == ref, t
+
+
+def test_gzip_members_with_unusual_xfl_os_bytes(gpu_ctx, monkeypatch):
+    """The boundary search first trusts only headers with the XFL / OS bytes real writers emit
+    (LA_GZ_INDEX_STRICT).  A stream whose headers carry other values (the reference accepts any,
+    gzip.c:128-239) must still come out whole: the filter notices the passed-over header behind the
+    first member's trailer and goes on with every 1f 8b 08 as a candidate."""
+    import random
+    import oracle_lib as O
+    import streams as S
+    monkeypatch.setenv("LA_GPU_BATCH_MIB", "1")
+    rnd = random.Random(313)
+    words = [rnd.randbytes(rnd.randint(2, 9)) for _ in range(400)]
+    for xfl, osb, every in ((7, 77, 1), (0, 200, 1), (9, 3, 3)):
+        parts, plain = [], b""
+        for i in range(70):
+            d = b"".join(rnd.choice(words) for _ in range(rnd.randint(1, 12000)))
+            m = bytearray(S.gz_member(d, level=rnd.choice([1, 6, 9])))
+            if i % every == 0:
+                m[8], m[9] = xfl, osb
+            parts.append(bytes(m))
+            plain += d
+        img = b"".join(parts)
+        for tail in (b"", b"trailing junk that is not a member"):
+            out, res = O.gzip_stream_decode(img + tail, len(plain) + 64)
+            assert out.tobytes() == plain and res.rc == 0
+            r = la_api.cat(img + tail, read_size=rnd.choice([None, 4096]))
+            assert la_api.as_reference_tuple(r) == (plain, 0, ""), (xfl, osb, every, len(r.data), r.error)

@@ -43,6 +43,15 @@ from test_gpu_filters import (  # noqa: E402,F401
     test_gzip_metadata_snapshot,
     test_gzip_strict_mode_rejects_bad_crc,
     test_gzip_mutated_streams,
+    test_gzip_members_with_unusual_xfl_os_bytes,
+)
+from test_gpu_tar import (  # noqa: E402,F401
+    test_reference_tar_fixtures_list_like_the_reference_tests,
+    test_extract_fixtures_contents,
+    test_tarfile_written_archives_walk_entry_by_entry,
+    test_c4_shape_many_equal_entries,
+    test_damaged_tar_streams_fail_like_the_reference,
+    test_old_style_tar_and_number_forms,
 )
 
 
