@@ -20,6 +20,13 @@
  *     what follows, and never lie beyond the member's slot).
  * The wave-per-member kernel of la_inflate.hip stays the path for small batches
  * and for members whose slot is too small for wild copies.
+ *
+ * Tried and not kept: more waves per SIMD.  The tables of 256 lanes fill the CU's LDS, so one
+ * wave runs per SIMD.  With the long-code symbol list moved to global scratch (IL_SL_GLOBAL=1,
+ * 320 B per lane, two workgroups per CU), also with 6-bit / 5-bit fast tables (four per CU) or
+ * 128-lane workgroups, the entropy decode of 16 GiB went from 94.6 ms to 114 / 144 / 138 ms: the
+ * one wave already keeps its SIMD's issue slots busy (every lane's path is executed by the whole
+ * wave), a second wave only adds its instructions to the same queue and the longer code walks.
  */
 #include "la_dev.h"
 
@@ -29,7 +36,12 @@
 #ifndef LL_BITS
 #define LL_BITS 7
 #endif
+#ifndef DT_BITS
 #define DT_BITS 6
+#endif
+#ifndef IL_SL_GLOBAL
+#define IL_SL_GLOBAL 0	/* 1: the literal/length symbol list for long codes lives in global scratch, not LDS */
+#endif
 #ifndef IL_LIT_ROUNDS
 #define IL_LIT_ROUNDS 2
 #endif
@@ -50,7 +62,9 @@
  *       code-length code), DT_BITS wide, entry = symbol << 3 | length */
 struct il_lds {
 	uint16_t ll[1 << LL_BITS][IL_THREADS];
+#if !IL_SL_GLOBAL
 	uint8_t sl[288][IL_THREADS];
+#endif
 	uint8_t dt[1 << DT_BITS][IL_THREADS];
 };
 
@@ -207,8 +221,10 @@ __device__ int il_build(const uint8_t *lens, int n, lane_code &C, uint16_t *sort
 		if (l == 0) continue;
 		const uint32_t pos = p16_get(next_off, l);
 		p16_add(next_off, l, 1);
-		if (LL) {
+		if (LL && !IL_SL_GLOBAL) {
+#if !IL_SL_GLOBAL
 			T.sl[pos][tid] = (uint8_t)sy;
+#endif
 			if (sy < 256)
 				p16_add(C.nlow, l, 1);
 		} else {
@@ -265,8 +281,10 @@ __device__ __forceinline__ int il_decode(lane_bits &B, const lane_code &C, const
 	if (hit_len) {
 		lb_drop(B, (uint32_t)hit_len);
 		*used = (uint32_t)hit_len;
+#if !IL_SL_GLOBAL
 		if (LL)
 			return (int)T.sl[hit_idx][tid] | hit_hi;
+#endif
 		return sorted[hit_idx];
 	}
 	{

@@ -67,3 +67,70 @@ def test_oracle_and_walkers_under_asan_ubsan(tmp_path):
     out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     assert "sanitized runs:" in out.stdout
+
+
+FILTER_DRIVER = r'''
+import ctypes as C, io, os, random, sys, tarfile
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
+os.environ["LA_GPU_BATCH_MIB"] = "1"
+import la_api
+la_api.use_library(C.CDLL(os.path.join(ROOT, "tests", "mock_gpu", "libla_host_mock_asan.so")))
+import streams as S
+from test_gpu_filters import _dependent_frame
+from test_gpu_tar import _make_tar, _gz_members, _lz4_frames
+
+rnd = random.Random(77)
+n = 0
+def mutations(img, k):
+    yield img
+    for _ in range(k):
+        m = bytearray(img)
+        for _ in range(rnd.randint(1, 3)):
+            m[rnd.randrange(len(m))] = rnd.getrandbits(8)
+        if rnd.random() < 0.3:
+            m = m[:rnd.randrange(1, len(m))]
+        yield bytes(m)
+
+tar, _ = _make_tar(random.Random(3), 25, sizes=[0, 1, 511, 513, 3000, 70000])
+for img in (tar, _gz_members(tar), _lz4_frames(tar)):
+    for m in mutations(img, 25):
+        la_api.list_entries(m, read_size=rnd.choice([None, 512, 4096]), skip_every=rnd.choice([0, 2]))
+        la_api.cat(m, read_size=rnd.choice([None, 1000]))
+        n += 2
+# header-field fuzz on the plain tar: every byte of the first header in turn takes odd values
+for pos in range(0, 512, 3):
+    for v in (0, 0x20, 0x37, 0x38, 0x80, 0xff):
+        m = bytearray(tar); m[pos] = v
+        la_api.list_entries(bytes(m)); n += 1
+words = [rnd.randbytes(rnd.randint(2, 11)) for _ in range(300)]
+data = b"".join(rnd.choice(words) for _ in range(500000))[:3 << 20]
+dep, _ = _dependent_frame(data, flg=0x54)
+big, _ = S.synth_lz4_stream(5, 0, 40, blocks_per_frame=16, block_size=65536, nthreads=2)
+gz = b"".join(S.gz_member(data[o:o + 50000], level=1) for o in range(0, len(data), 50000))
+odd = bytearray(gz); odd[8], odd[9] = 9, 99
+for img in (dep, big.tobytes(), gz, bytes(odd)):
+    for m in mutations(img, 12):
+        la_api.cat(m, read_size=rnd.choice([None, 65536, 1000])); n += 1
+print("sanitized filter runs:", n)
+'''
+
+
+def test_filters_read_core_and_tar_walker_under_asan_ubsan(tmp_path):
+    """The whole host side (read core, both filters with their window / carry / history arithmetic, the ustar
+    walker) on top of the CPU mock of the device ABI, everything built with ASan + UBSan, over clean, mutated and
+    truncated tar / tar.gz / tar.lz4 / multi-window lz4 and gzip streams."""
+    host = os.path.join(ROOT, "libarchive_amd", "host")
+    mock = os.path.join(ROOT, "tests", "mock_gpu")
+    orc = os.path.join(ROOT, "oracle")
+    srcs = [os.path.join(host, f) for f in ("la_lz4_index.c", "la_gzip_index.c", "la_read_core.c", "la_format_tar.c",
+                                            "la_filter_lz4.c", "la_filter_gzip.c")]
+    srcs += [os.path.join(mock, "la_gpu_mock.c")] + [os.path.join(orc, f) for f in ("orc_hash.c", "orc_lz4.c", "orc_inflate.c")]
+    subprocess.check_call(["gcc", "-O1", "-g", "-fPIC", "-std=gnu11", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+                           "-I" + os.path.join(ROOT, "include"), "-shared", "-o", os.path.join(mock, "libla_host_mock_asan.so")] + srcs)
+    libasan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"]).decode().strip()
+    env = dict(os.environ, LD_PRELOAD=libasan, ASAN_OPTIONS="detect_leaks=0:halt_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
+    script = tmp_path / "drv_filters.py"
+    script.write_text("ROOT = %r\n" % ROOT + FILTER_DRIVER)
+    out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-4000:])
+    assert "sanitized filter runs:" in out.stdout

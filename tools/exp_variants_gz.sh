@@ -4,6 +4,6 @@ cp libarchive_amd/csrc/libla_gpu.so /tmp/libla_gpu_keep.so
 for v in "$@"; do
   cp libarchive_amd/csrc/libla_gpu_$v.so libarchive_amd/csrc/libla_gpu.so
   echo "== $v"
-  timeout -k 5 200 python bench.py --workload gzip --gib 4 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['bit_exact'], d['ms_per_step'], d['phases_ms'])"
+  timeout -k 5 200 python bench.py --workload gzip --gib ${GIB:-4} --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['bit_exact'], d['ms_per_step'], d['phases_ms'])"
 done
 cp /tmp/libla_gpu_keep.so libarchive_amd/csrc/libla_gpu.so
