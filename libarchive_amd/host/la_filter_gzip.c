@@ -232,8 +232,8 @@ static int gzip_run_batch(struct archive_read_filter *self, struct gzip_private 
 		return gz_gpu_fail(self, st, "device allocation");
 	uint8_t *T = st->d_tabs;
 	const double b0 = st->trace ? gz_now() : 0;
-	if (la_gpu_memcpy_h2d(st->gpu, st->d_src, st->stage, src_len) != LA_OK ||
-	    la_gpu_memcpy_h2d(st->gpu, T + o_mem, x->members, (size_t)n * sizeof(la_gz_member)) != LA_OK)
+	/* (the compressed bytes are already on their way: gzip_filter_read) */
+	if (la_gpu_memcpy_h2d(st->gpu, T + o_mem, x->members, (size_t)n * sizeof(la_gz_member)) != LA_OK)
 		return gz_gpu_fail(self, st, "host to device copy");
 	la_gz_batch bt;
 	memset(&bt, 0, sizeof(bt));
@@ -467,6 +467,13 @@ static ssize_t gzip_filter_read(struct archive_read_filter *self, const void **p
 			__archive_read_filter_consume(self->upstream, (int64_t)n);
 		}
 		const double t1 = st->trace ? gz_now() : 0;
+		/* the window goes to the device while the host looks for the member boundaries in it
+		 * (stream-ordered copy from the pinned window; nothing below writes to [0, stage_len)
+		 * before the batch has been waited for) */
+		if (st->stage_len &&
+		    (gz_grow_dev(st, &st->d_src, &st->d_src_cap, st->stage_len + 64) < 0 ||
+		     la_gpu_memcpy_h2d(st->gpu, st->d_src, st->stage, st->stage_len) != LA_OK))
+			return gz_gpu_fail(self, st, "host to device copy");
 		la_gz_index idx;
 		if (la_gz_index_build3(st->stage, st->stage_len, st->upstream_eof, st->hint_skip, st->hint_cap,
 		    st->loose ? 0 : LA_GZ_INDEX_STRICT, &idx) != 0) {
@@ -476,6 +483,8 @@ static ssize_t gzip_filter_read(struct archive_read_filter *self, const void **p
 		if (idx.n == 0) {
 			int kind = idx.end_kind;
 			la_gz_index_free(&idx);
+			if (la_gpu_sync(st->gpu) != LA_OK)	/* the upload above: the window may move now */
+				return gz_gpu_fail(self, st, "host to device copy");
 			if (kind == LA_END_NEED_MORE) {
 				if (st->upstream_eof) { st->eof = 1; continue; }
 				if (!st->loose) {

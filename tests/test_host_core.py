@@ -131,3 +131,49 @@ def test_gzip_walker_bgzf_and_speculative():
     # a window that ends inside the last member asks for more input
     n, end, consumed, _, _, _ = walk(img2[:-10], at_eof=0)
     assert end == N.LA_END_NEED_MORE and n == 2
+
+
+_SCAN_DRIVER = r'''
+import random, sys, os
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import libarchive_amd as la
+import streams as S
+rnd = random.Random(11)
+total = 0
+for t in range(120):
+    parts = []
+    for k in range(rnd.randint(1, 12)):
+        d = rnd.randbytes(rnd.choice([0, 1, 30, 31, 32, 33, 63, 64, 65, 500, 5000]))
+        m = bytearray(S.gz_member(d, level=rnd.choice([0, 6])))
+        if rnd.random() < 0.4 and len(m) > 40:        # false 1f 8b 08 (and near misses) inside the deflate data
+            q = rnd.randrange(12, len(m) - 12)
+            m[q:q + 3] = rnd.choice([b"\x1f\x8b\x08", b"\x1f\x8b\x07", b"\x1f\x1f\x8b", b"\x1f\x8b\x08"])
+            m[q + 3] = rnd.choice([0, 0, 8, 0x20])
+        parts.append(bytes(m))
+    img = np.frombuffer(b"".join(parts) + rnd.randbytes(rnd.randint(0, 40)), dtype=np.uint8)
+    for at_eof in (True, False):
+        idx = la.gz_index(img, at_eof=at_eof)
+        print(t, at_eof, idx.end_kind, idx.consumed, [(int(m["src_off"]), int(m["src_len"])) for m in idx.members])
+        total += len(idx.members)
+print("members", total)
+'''
+
+
+def test_gzip_boundary_scan_vector_and_fallback_agree(tmp_path):
+    """The member-boundary search has an AVX2 two-byte compare and a memchr fallback (LA_NO_AVX2=1): the same
+    member tables from both, on streams with false magics and near misses planted at random alignments."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "scan.py"
+    script.write_text("ROOT = %r\n" % root + _SCAN_DRIVER)
+    outs = []
+    for no_avx2 in (False, True):
+        env = dict(os.environ)
+        if no_avx2:
+            env["LA_NO_AVX2"] = "1"
+        out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-3000:]
+        outs.append(out.stdout)
+    assert outs[0] == outs[1]
+    assert int(outs[0].strip().rsplit(" ", 1)[1]) > 500
