@@ -460,7 +460,12 @@ static ssize_t gzip_filter_read(struct archive_read_filter *self, const void **p
 			size_t n = (size_t)avail;
 			if (n > st->batch_bytes - st->stage_len)
 				n = st->batch_bytes - st->stage_len;
-			if (gz_grow_pinned(st, &st->stage, &st->stage_cap, st->stage_len + n, st->stage_len) < 0)
+			/* a stream that has already filled 8 MiB gets the whole window at once instead of
+			 * five more rounds of pin-a-bigger-buffer-and-copy */
+			size_t want = st->stage_len + n;
+			if (want > ((size_t)8 << 20) && want < st->batch_bytes)
+				want = st->batch_bytes;
+			if (gz_grow_pinned(st, &st->stage, &st->stage_cap, want, st->stage_len) < 0)
 				return gz_gpu_fail(self, st, "pinned staging allocation");
 			memcpy(st->stage + st->stage_len, up, n);
 			st->stage_len += n;
