@@ -37,6 +37,8 @@ extern "C" {
 #define ARCHIVE_FORMAT_EMPTY 0x60000
 #define ARCHIVE_FORMAT_TAR        0x30000	/* archive.h:353-357 */
 #define ARCHIVE_FORMAT_TAR_USTAR  (ARCHIVE_FORMAT_TAR | 1)
+#define ARCHIVE_FORMAT_TAR_PAX_INTERCHANGE (ARCHIVE_FORMAT_TAR | 2)
+#define ARCHIVE_FORMAT_TAR_GNUTAR (ARCHIVE_FORMAT_TAR | 4)
 
 struct archive;
 struct archive_entry;
@@ -53,7 +55,7 @@ int  archive_read_support_filter_lz4(struct archive *);				/* archive.h:469 */
 int  archive_read_support_filter_none(struct archive *);
 int  archive_read_support_format_raw(struct archive *);
 int  archive_read_support_format_empty(struct archive *);
-int  archive_read_support_format_tar(struct archive *);			/* ustar / old tar only, la_format_tar.c */
+int  archive_read_support_format_tar(struct archive *);			/* ustar, old tar, GNU and pax names/sizes; no sparse (la_format_tar.c) */
 int  archive_read_support_format_all(struct archive *);			/* the formats of this slice: tar + empty */
 
 int  archive_read_open(struct archive *, void *client_data, archive_open_callback *,

@@ -17,8 +17,17 @@
  *                                    padding; "Truncated tar archive detected while reading data")
  *   skip                   :670-691
  *
- * Out of this slice on purpose: pax 'x'/'g', GNU 'L'/'K'/'V' and sparse entries, Solaris ACLs, mac metadata,
- * character-set conversion.  Such a header is refused with a message saying so rather than half-read.
+ *   GNU headers            :2927-3023 (magic "ustar  \0": no prefix field), 'L' long name / 'K' long link :1172-1221,
+ *                          :1251-1316 (body -> string, "Truncated archive detected while reading metadata"),
+ *                          'V' volume header :1227-1245
+ *   pax 'x' / 'X' / 'g'    :1846-2100 (records "<len> <key>=<value>\n"); of the keys only path, size and mtime
+ *                          reach what this slice exposes; 'g' is read and ignored
+ *   sequence rules         :748-986 (one of each special header per entry, EOF or a bad checksum after a special
+ *                          header is fatal: "Damaged tar archive (end-of-archive within a sequence of headers)")
+ *
+ * Out of this slice on purpose: sparse entries (GNU 'S', GNU.sparse.* pax keys), Solaris ACLs ('A'), mac metadata,
+ * character-set conversion, names longer than the entry's 1023-byte buffer.  Such input is refused with a message
+ * saying so rather than half-read.
  */
 #include <errno.h>
 #include <limits.h>
@@ -40,6 +49,10 @@ struct tar_info {
 	int64_t entry_padding;
 	int64_t entry_offset;
 	int64_t disk_size;
+	/* what the special headers in front of a regular header said (reset per entry) */
+	int     have_path, have_size, have_mtime;
+	char    path[1024];
+	int64_t pax_size, pax_mtime;
 };
 
 static int block_is_null(const char *h)
@@ -195,14 +208,14 @@ static int header_fields(struct archive_read *a, struct tar_info *tar, struct ar
 	size_t k = field_len(u->name, sizeof(u->name));
 	memcpy(path + n, u->name, k);
 	path[n + k] = 0;
-	archive_entry_set_pathname(entry, path);
+	archive_entry_set_pathname(entry, tar->have_path ? tar->path : path);
 
 	int64_t mode = tar_atol(u->mode, sizeof(u->mode));
 	entry->mode = (unsigned)mode & 07777;
-	entry->mtime = tar_atol(u->mtime, sizeof(u->mtime));
+	entry->mtime = tar->have_mtime ? tar->pax_mtime : tar_atol(u->mtime, sizeof(u->mtime));
 	entry->mtime_set = 1;
 
-	tar->disk_size = tar_atol(u->size, sizeof(u->size));
+	tar->disk_size = tar->have_size ? tar->pax_size : tar_atol(u->size, sizeof(u->size));	/* :1378-1383, :1403-1408 */
 	if (tar->disk_size < 0) {
 		archive_set_error(&a->archive, ARCHIVE_ERRNO_MISC, "Tar entry has negative file size");
 		return ARCHIVE_FATAL;
@@ -232,68 +245,246 @@ static int header_fields(struct archive_read *a, struct tar_info *tar, struct ar
 	return ARCHIVE_OK;
 }
 
+/* body of a special header -> buf (NUL terminated); the body and its padding join *unconsumed (:1251-1316) */
+static int body_to_string(struct archive_read *a, const struct ustar_hdr *u, char *buf, size_t cap, size_t *len,
+    int64_t *unconsumed)
+{
+	int64_t size = tar_atol(u->size, sizeof(u->size));
+	if (size < 0 || size > entry_limit) {
+		archive_set_error(&a->archive, EINVAL, "Special header has invalid size: %lld", (long long)size);
+		return ARCHIVE_FATAL;
+	}
+	if (size > 1048576) {	/* pathname_limit :244 */
+		int64_t to_consume = (size + 511) & ~(int64_t)511;
+		flush_unconsumed(a, unconsumed);
+		if (to_consume != __archive_read_consume(a, to_consume))
+			return ARCHIVE_FATAL;
+		archive_set_error(&a->archive, EINVAL, "Special header too large: %lld > 1MiB", (long long)size);
+		*len = 0;
+		buf[0] = 0;
+		return ARCHIVE_WARN;
+	}
+	flush_unconsumed(a, unconsumed);
+	const char *src = __archive_read_ahead(a, (size_t)size, NULL);
+	if (src == NULL && size > 0) {
+		archive_set_error(&a->archive, EINVAL, "Truncated archive detected while reading metadata");
+		return ARCHIVE_FATAL;
+	}
+	if ((size_t)size >= cap) {
+		archive_set_error(&a->archive, ARCHIVE_ERRNO_FILE_FORMAT,
+		    "tar metadata of %lld bytes is outside this slice (at most %zu)", (long long)size, cap - 1);
+		return ARCHIVE_FATAL;
+	}
+	if (size)
+		memcpy(buf, src, (size_t)size);
+	buf[size] = 0;
+	*len = (size_t)size;
+	*unconsumed += size + (0x1ff & (-size));
+	return ARCHIVE_OK;
+}
+
+/* pax records "<decimal length> <key>=<value>\n" (:1846-2100); keys this slice exposes: path, size, mtime */
+static int pax_records(struct archive_read *a, struct tar_info *tar, const char *p, size_t n, int global)
+{
+	while (n > 0) {
+		size_t l = 0, i = 0;
+		while (i < n && p[i] >= '0' && p[i] <= '9' && i < 10)
+			l = l * 10 + (size_t)(p[i++] - '0');
+		if (i == 0 || i >= n || p[i] != ' ' || l <= i + 1 || l > n || p[l - 1] != '\n') {
+			archive_set_error(&a->archive, ARCHIVE_ERRNO_MISC, "Ignoring malformed pax extended attributes");
+			return ARCHIVE_WARN;
+		}
+		const char *key = p + i + 1, *end = p + l - 1;
+		const char *eq = memchr(key, '=', (size_t)(end - key));
+		if (eq == NULL) {
+			archive_set_error(&a->archive, ARCHIVE_ERRNO_MISC, "Invalid pax extended attributes");
+			return ARCHIVE_WARN;
+		}
+		const size_t kl = (size_t)(eq - key), vl = (size_t)(end - eq - 1);
+		const char *v = eq + 1;
+		if (!global) {
+			if (kl >= 11 && memcmp(key, "GNU.sparse.", 11) == 0) {
+				archive_set_error(&a->archive, ARCHIVE_ERRNO_FILE_FORMAT, "sparse tar entries are outside this slice");
+				return ARCHIVE_FATAL;
+			}
+			if (kl == 4 && memcmp(key, "path", 4) == 0) {
+				if (vl >= sizeof(tar->path)) {
+					archive_set_error(&a->archive, ARCHIVE_ERRNO_FILE_FORMAT,
+					    "pathname of %zu bytes is outside this slice (at most %zu)", vl, sizeof(tar->path) - 1);
+					return ARCHIVE_FATAL;
+				}
+				memcpy(tar->path, v, vl);
+				tar->path[vl] = 0;
+				tar->have_path = 1;
+			} else if (kl == 4 && memcmp(key, "size", 4) == 0) {
+				tar->pax_size = atol_base_n(v, vl, 10);
+				tar->have_size = 1;
+			} else if (kl == 5 && memcmp(key, "mtime", 5) == 0) {
+				tar->pax_mtime = atol_base_n(v, vl, 10);	/* whole seconds; the fraction is not exposed */
+				tar->have_mtime = 1;
+			}
+		}
+		p += l;
+		n -= l;
+	}
+	return ARCHIVE_OK;
+}
+
+static int err_combine(int a, int b) { return a < b ? a : b; }
+
 static int tar_read_header(struct archive_read *a, struct archive_entry *entry)
 {
 	struct tar_info *tar = a->format->data;
 	int64_t unconsumed = 0;
 	ssize_t bytes;
 	const char *h;
+	int err = ARCHIVE_OK, eof_fatal = 0;
+	unsigned seen = 0;	/* 1 'g', 2 'K', 4 'L', 8 'V', 16 'x'/'X' */
+	char *meta = NULL;	/* body of a special header */
+	const size_t meta_cap = 65536;
 
 	tar->entry_offset = 0;
+	tar->have_path = tar->have_size = tar->have_mtime = 0;
 	if (a->archive.archive_format_name == NULL || (a->archive.archive_format & 0xff0000) != ARCHIVE_FORMAT_TAR) {
 		a->archive.archive_format = ARCHIVE_FORMAT_TAR;
 		a->archive.archive_format_name = "tar";
 	}
 
-	h = __archive_read_ahead(a, 512, &bytes);
-	if (bytes == 0)
-		return ARCHIVE_EOF;
-	if (h == NULL) {
-		archive_set_error(&a->archive, ARCHIVE_ERRNO_FILE_FORMAT,
-		    "Truncated tar archive detected while reading next header");
-		return ARCHIVE_FATAL;
-	}
-	unconsumed = 512;
-	if (h[0] == 0 && block_is_null(h)) {
+	for (;;) {
 		flush_unconsumed(a, &unconsumed);
-		h = __archive_read_ahead(a, 512, NULL);
-		if (h != NULL && h[0] == 0 && block_is_null(h))
-			__archive_read_consume(a, 512);
-		archive_clear_error(&a->archive);
-		return ARCHIVE_EOF;
-	}
-	if (!checksum_ok(h)) {
-		flush_unconsumed(a, &unconsumed);
-		archive_set_error(&a->archive, EINVAL, "Damaged tar archive (bad header checksum)");
-		return ARCHIVE_RETRY;
-	}
-
-	const struct ustar_hdr *u = (const struct ustar_hdr *)h;
-	int r;
-	switch (u->typeflag[0]) {
-	case 'A': case 'g': case 'K': case 'L': case 'V': case 'X': case 'x':
-		archive_set_error(&a->archive, ARCHIVE_ERRNO_FILE_FORMAT,
-		    "tar extension header '%c' is outside this ustar slice", u->typeflag[0]);
-		return ARCHIVE_FATAL;
-	default:
-		if (memcmp(u->magic, "ustar  \0", 8) == 0) {
+		h = __archive_read_ahead(a, 512, &bytes);
+		if (bytes == 0) {
+			free(meta);
+			if (eof_fatal) {
+				archive_set_error(&a->archive, EINVAL,
+				    "Damaged tar archive (end-of-archive within a sequence of headers)");
+				return ARCHIVE_FATAL;
+			}
+			return ARCHIVE_EOF;
+		}
+		if (h == NULL) {
+			free(meta);
 			archive_set_error(&a->archive, ARCHIVE_ERRNO_FILE_FORMAT,
-			    "GNU tar headers are outside this ustar slice");
+			    "Truncated tar archive detected while reading next header");
 			return ARCHIVE_FATAL;
+		}
+		unconsumed = 512;
+		if (h[0] == 0 && block_is_null(h)) {
+			flush_unconsumed(a, &unconsumed);
+			h = __archive_read_ahead(a, 512, NULL);
+			if (h != NULL && h[0] == 0 && block_is_null(h))
+				__archive_read_consume(a, 512);
+			archive_clear_error(&a->archive);
+			free(meta);
+			return ARCHIVE_EOF;
+		}
+		if (!checksum_ok(h)) {
+			flush_unconsumed(a, &unconsumed);
+			free(meta);
+			archive_set_error(&a->archive, EINVAL, "Damaged tar archive (bad header checksum)");
+			return eof_fatal ? ARCHIVE_FATAL : ARCHIVE_RETRY;
+		}
+
+		const struct ustar_hdr *u = (const struct ustar_hdr *)h;
+		const char t = u->typeflag[0];
+		int r = ARCHIVE_OK;
+		if (t == 'g' || t == 'K' || t == 'L' || t == 'V' || t == 'X' || t == 'x') {
+			const unsigned bit = t == 'g' ? 1u : t == 'K' ? 2u : t == 'L' ? 4u : t == 'V' ? 8u : 16u;
+			if (seen & bit) {
+				if (t == 'g' || t == 'x' || t == 'X') {
+					archive_set_error(&a->archive, ARCHIVE_ERRNO_MISC,
+					    t == 'g' ? "Redundant 'g' header" : t == 'x' ? "Redundant 'x' header" : "Redundant 'X'/'x' header");
+					free(meta);
+					return ARCHIVE_FATAL;
+				}
+				archive_set_error(&a->archive, ARCHIVE_ERRNO_MISC,
+				    t == 'K' ? "Damaged archive: Redundant 'K' headers may cause linknames to be incorrect"
+				    : t == 'L' ? "Damaged archive: Redundant 'L' headers may cause filenames to be incorrect"
+				    : "Redundant 'V' header");
+				err = err_combine(err, ARCHIVE_WARN);
+			}
+			seen |= bit;
+			if (t == 'K' || t == 'L' || t == 'V') {
+				a->archive.archive_format = ARCHIVE_FORMAT_TAR_GNUTAR;
+				a->archive.archive_format_name = "GNU tar format";
+			} else {
+				a->archive.archive_format = ARCHIVE_FORMAT_TAR_PAX_INTERCHANGE;
+				a->archive.archive_format_name = t == 'X' ? "POSIX pax interchange format (Sun variant)"
+				    : "POSIX pax interchange format";
+			}
+			if (t == 'V') {		/* volume label: the body is skipped (:1227-1245) */
+				int64_t size = tar_atol(u->size, sizeof(u->size));
+				if (size < 0 || size > 1048576) {
+					free(meta);
+					return ARCHIVE_FATAL;
+				}
+				unconsumed += (size + 511) & ~(int64_t)511;
+			} else {
+				size_t len = 0;
+				if (meta == NULL && (meta = malloc(meta_cap)) == NULL) {
+					archive_set_error(&a->archive, ENOMEM, "No memory");
+					return ARCHIVE_FATAL;
+				}
+				const struct ustar_hdr keep = *u;	/* the look-ahead below may move the window */
+				r = body_to_string(a, &keep, meta, meta_cap, &len, &unconsumed);
+				if (r == ARCHIVE_OK && t == 'L') {
+					len = strlen(meta);		/* GNU tar writes the terminating NUL into the body */
+					if (len >= sizeof(tar->path)) {
+						archive_set_error(&a->archive, ARCHIVE_ERRNO_FILE_FORMAT,
+						    "pathname of %zu bytes is outside this slice (at most %zu)", len, sizeof(tar->path) - 1);
+						r = ARCHIVE_FATAL;
+					} else {
+						memcpy(tar->path, meta, len + 1);
+						tar->have_path = 1;
+					}
+				} else if (r == ARCHIVE_OK && (t == 'x' || t == 'X' || t == 'g')) {
+					r = pax_records(a, tar, meta, len, t == 'g');
+				}
+			}
+			err = err_combine(err, r);
+			if (err == ARCHIVE_FATAL) {
+				free(meta);
+				return err;
+			}
+			if (seen & ~(8u | 1u))	/* after anything but 'V' and 'g' a regular header has to follow (:981-984) */
+				eof_fatal = 1;
+			continue;
+		}
+		if (t == 'A') {
+			free(meta);
+			archive_set_error(&a->archive, ARCHIVE_ERRNO_FILE_FORMAT, "Solaris tar ACL headers are outside this slice");
+			return ARCHIVE_FATAL;
+		}
+
+		/* a regular header: old tar, ustar or GNU */
+		if (memcmp(u->magic, "ustar  \0", 8) == 0) {
+			a->archive.archive_format = ARCHIVE_FORMAT_TAR_GNUTAR;
+			a->archive.archive_format_name = "GNU tar format";
+			if (t == 'S' || h[386] != 0) {	/* sparse[0].offset[0] (:3007) */
+				free(meta);
+				archive_set_error(&a->archive, ARCHIVE_ERRNO_FILE_FORMAT, "sparse tar entries are outside this slice");
+				return ARCHIVE_FATAL;
+			}
+			r = header_fields(a, tar, entry, u, 0);
 		} else if (memcmp(u->magic, "ustar", 5) == 0) {
-			a->archive.archive_format = ARCHIVE_FORMAT_TAR_USTAR;
-			a->archive.archive_format_name = "POSIX ustar format";
+			if (a->archive.archive_format != ARCHIVE_FORMAT_TAR_PAX_INTERCHANGE) {
+				a->archive.archive_format = ARCHIVE_FORMAT_TAR_USTAR;
+				a->archive.archive_format_name = "POSIX ustar format";
+			}
 			r = header_fields(a, tar, entry, u, 1);
 		} else {
 			a->archive.archive_format = ARCHIVE_FORMAT_TAR;
 			a->archive.archive_format_name = "tar (non-POSIX)";
 			r = header_fields(a, tar, entry, u, 0);
 		}
+		err = err_combine(err, r);
+		break;
 	}
+	free(meta);
 	flush_unconsumed(a, &unconsumed);
-	if (r < ARCHIVE_WARN)
+	if (err < ARCHIVE_WARN)
 		return ARCHIVE_FATAL;
-	if (r == ARCHIVE_OK && entry->filetype == AE_IFREG) {
+	if (err == ARCHIVE_OK && entry->filetype == AE_IFREG) {
 		size_t l = strlen(entry->pathname);
 		if (l > 0 && entry->pathname[l - 1] == '/') {
 			entry->filetype = AE_IFDIR;
@@ -301,7 +492,7 @@ static int tar_read_header(struct archive_read *a, struct archive_entry *entry)
 			tar->entry_padding = 0;
 		}
 	}
-	return r;
+	return err;
 }
 
 static int tar_read_data(struct archive_read *a, const void **buff, size_t *size, int64_t *offset)

@@ -182,14 +182,18 @@ def test_damaged_tar_streams_fail_like_the_reference(gpu_ctx):
     r = la_api.list_entries(_gz_members(tar[:o] + bytes(512) + tar[o:]))
     assert r.rc == ARCHIVE_EOF and len(r.entries) == sum(1 for _ in _headers_before(tar, o))
 
-    # extension headers are refused loudly, not half-read
+    # a special header with nothing behind it (:757-765)
     bio = io.BytesIO()
-    with tarfile.open(fileobj=bio, mode="w", format=tarfile.PAX_FORMAT) as t:
-        ti = tarfile.TarInfo("x" * 300)
+    with tarfile.open(fileobj=bio, mode="w", format=tarfile.GNU_FORMAT) as t:
+        ti = tarfile.TarInfo("y" * 300)
         ti.size = 3
         t.addfile(ti, io.BytesIO(b"abc"))
-    r = la_api.list_entries(_gz_members(bio.getvalue()))
-    assert r.rc == ARCHIVE_FATAL and "outside this ustar slice" in r.error
+    g = bio.getvalue()
+    assert g[156:157] == b"L"
+    r = la_api.list_entries(_gz_members(g[:1024]))          # 'L' header + its body, then the end of the stream
+    assert r.rc == ARCHIVE_FATAL and r.error == "Damaged tar archive (end-of-archive within a sequence of headers)"
+    r = la_api.list_entries(_gz_members(g[:700]))           # the long name itself is cut (:1267-1274)
+    assert r.rc == ARCHIVE_FATAL and r.error == "Truncated archive detected while reading metadata"
 
 
 def _headers_before(tar, limit):
@@ -230,3 +234,45 @@ def test_old_style_tar_and_number_forms(gpu_ctx):
     r = la_api.list_entries(_lz4_frames(old))
     assert r.rc == ARCHIVE_EOF and r.format == TAR_OLD and r.format_name == "tar (non-POSIX)"
     assert r.entries[0][5] == body
+
+
+TAR_PAX, TAR_GNU = 0x30002, 0x30004
+
+
+@pytest.mark.parametrize("fmt", ["gnu", "pax"])
+def test_gnu_and_pax_archives_with_long_names(gpu_ctx, fmt, monkeypatch):
+    """What GNU tar and bsdtar / Python write by default: GNU headers with 'L' long names
+    (archive_read_support_format_tar.c:2927-3023, :1206-1221) and pax 'x' records for path / size / mtime
+    (:1846-2100), in front of ordinary entries; listing and bodies as Python's tarfile reads them back."""
+    monkeypatch.setenv("LA_GPU_BATCH_MIB", "1")
+    rnd = random.Random(31)
+    pyfmt = tarfile.GNU_FORMAT if fmt == "gnu" else tarfile.PAX_FORMAT
+    bio = io.BytesIO()
+    with tarfile.open(fileobj=bio, mode="w", format=pyfmt) as t:
+        for i in range(40):
+            name = "f%d" % i
+            if i % 3 == 0:
+                name = "/".join("directory-%d-%d" % (i, k) for k in range(rnd.randint(8, 40))) + "/leaf-%d.bin" % i
+            body = rnd.randbytes(rnd.choice([0, 5, 512, 700, 66000]))
+            ti = tarfile.TarInfo(name)
+            ti.size = len(body)
+            ti.mtime = 1700000000 + i + (0.25 if fmt == "pax" and i % 4 == 0 else 0)
+            ti.mode = 0o640
+            t.addfile(ti, io.BytesIO(body))
+        d = tarfile.TarInfo("z" * 150 + "/")
+        d.type = tarfile.DIRTYPE
+        t.addfile(d)
+    tar = bio.getvalue()
+    with tarfile.open(fileobj=io.BytesIO(tar)) as t:
+        want = [(m.name + ("/" if m.isdir() else ""), m.size if m.isfile() else 0, int(m.mtime),
+                 t.extractfile(m).read() if m.isfile() else b"") for m in t.getmembers()]
+    assert any(len(w[0]) > 256 for w in want)
+    for image in (_gz_members(tar), _lz4_frames(tar)):
+        for skip_every in (0, 2):
+            r = la_api.list_entries(image, read_size=rnd.choice([None, 4096]), skip_every=skip_every)
+            assert r.rc == ARCHIVE_EOF and r.error is None, (r.rc, r.error)
+            assert r.format == (TAR_GNU if fmt == "gnu" else TAR_PAX)
+            assert [(e[0], e[1], e[4]) for e in r.entries] == [(w[0], w[1], w[2]) for w in want]
+            for i, (e, w) in enumerate(zip(r.entries, want), 1):
+                if not (skip_every and i % skip_every == 0):
+                    assert e[5] == w[3]

@@ -102,6 +102,19 @@ for pos in range(0, 512, 3):
     for v in (0, 0x20, 0x37, 0x38, 0x80, 0xff):
         m = bytearray(tar); m[pos] = v
         la_api.list_entries(bytes(m)); n += 1
+# GNU 'L' and pax 'x' headers: mutated special headers and bodies
+for pyfmt in (tarfile.GNU_FORMAT, tarfile.PAX_FORMAT):
+    bio = io.BytesIO()
+    with tarfile.open(fileobj=bio, mode="w", format=pyfmt) as t:
+        for i in range(6):
+            ti = tarfile.TarInfo(("long-name-%d/" % i) * rnd.randint(1, 60) + "leaf")
+            ti.size = 700; ti.mtime = 1700000000.5
+            t.addfile(ti, io.BytesIO(bytes(700)))
+    sp = bio.getvalue()
+    for m in mutations(sp, 150):
+        la_api.list_entries(m, read_size=rnd.choice([None, 512])); n += 1
+    for cut in range(0, min(len(sp), 6000), 97):
+        la_api.list_entries(sp[:cut]); n += 1
 words = [rnd.randbytes(rnd.randint(2, 11)) for _ in range(300)]
 data = b"".join(rnd.choice(words) for _ in range(500000))[:3 << 20]
 dep, _ = _dependent_frame(data, flg=0x54)
