@@ -276,3 +276,31 @@ def test_gnu_and_pax_archives_with_long_names(gpu_ctx, fmt, monkeypatch):
             for i, (e, w) in enumerate(zip(r.entries, want), 1):
                 if not (skip_every and i % skip_every == 0):
                     assert e[5] == w[3]
+
+
+def test_archives_written_by_the_system_tar(gpu_ctx, tmp_path):
+    """Interop: what `tar -czf` of this image writes (GNU format, one gzip member) and its --format=ustar /
+    --format=posix variants, listed entry by entry; names, sizes and bodies as the files on disk."""
+    import shutil
+    import subprocess
+    if shutil.which("tar") is None:
+        pytest.skip("no tar(1) in this image")
+    rnd = random.Random(8)
+    root = tmp_path / "tree"
+    (root / "sub" / ("deep-" * 30)).mkdir(parents=True)
+    files = {}
+    for i, rel in enumerate(["a.txt", "sub/b.bin", "sub/" + "deep-" * 30 + "/" + "n" * 120, "empty"]):
+        body = b"" if rel == "empty" else rnd.randbytes(rnd.choice([10, 5000, 80000]))
+        (root / rel).write_bytes(body)
+        files["tree/" + rel] = body
+    for fmt in ("gnu", "ustar", "posix"):
+        out = tmp_path / ("t_%s.tar.gz" % fmt)
+        r = subprocess.run(["tar", "--format=" + fmt, "-czf", str(out), "-C", str(tmp_path), "tree"], capture_output=True)
+        if r.returncode != 0:
+            assert fmt == "ustar", r.stderr      # the 120-byte leaf under a long directory may not fit ustar
+            continue
+        res = la_api.list_entries(None, filename=str(out), block_size=65536)
+        assert res.rc == ARCHIVE_EOF and res.error is None, (fmt, res.rc, res.error)
+        got = {e[0]: e[5] for e in res.entries if e[2] == AE_IFREG}
+        assert got == files, (fmt, sorted(got), sorted(files))
+        assert sum(1 for e in res.entries if e[2] == AE_IFDIR) == 3

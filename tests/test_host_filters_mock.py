@@ -53,6 +53,7 @@ from test_gpu_tar import (  # noqa: E402,F401
     test_damaged_tar_streams_fail_like_the_reference,
     test_old_style_tar_and_number_forms,
     test_gnu_and_pax_archives_with_long_names,
+    test_archives_written_by_the_system_tar,
 )
 
 
