@@ -234,9 +234,9 @@ typedef struct la_gz_batch {
 } la_gz_batch;
 
 #define LA_GZ_OPT_NO_VERIFY   1u	/* do not compare the trailer (reference behaviour) */
-#define LA_GZ_OPT_WAVE_KERNEL 2u	/* force the wave-per-member kernel (default: lane-per-member from 512 members up) */
+#define LA_GZ_OPT_WAVE_KERNEL 2u	/* force the wave-per-member kernel (default: lane-per-member from 8192 members up) */
 #define LA_GZ_OPT_LANE_KERNEL 4u	/* force the in-place lane-per-member kernel */
-#define LA_GZ_OPT_TWO_PHASE   8u	/* force entropy decode + LDS-window expand (the default from 512 members up) */
+#define LA_GZ_OPT_TWO_PHASE   8u	/* force entropy decode + LDS-window expand (the default from 8192 members up) */
 
 int la_gpu_gzip_decode(la_gpu_ctx *ctx, const la_gz_batch *batch);
 

@@ -17,13 +17,13 @@
  * Accept/reject rules follow zlib 1.2.11 (see oracle/orc_inflate.c).
  * Byte/integer work; no MFMA.
  *
- * Speed: one 64 KiB member takes about 21.8 ms here whatever the batch size, 2.6 MiB/s for a lone
- * member (tools/measure_single_member_gz.py) -- the serial chain costs ~2 400 cycles per symbol.
- * Tried and not kept: building the output in a 64 KiB LDS ring per wave (match copies LDS to LDS,
- * 16-byte drains to the slab) instead of store / fence / load through global memory: parity green,
- * time unchanged (12.35 s for a 32 MiB member before and after), so the round trips through global
- * memory are not where the chain spends its time; the per-symbol scalar work (window refill through
- * v_readlane, LDS table look, readfirstlane, four constant-table loads per match) is next to look at.
+ * Speed (one 64 KiB member, ms): 21.8 at first -- the bit reader and the window lived in SCRATCH memory
+ * because inflate_codes() was an out-of-line function taking them by reference (scratch_load /
+ * scratch_store + s_waitcnt vmcnt(0) on every refill); inlined: 9.1.  Length / distance bases by
+ * arithmetic instead of constant-table loads and no division for non-overlapping copies: see
+ * DESIGN.md §5.  Tried and not kept: the output in a 64 KiB LDS ring per wave (match copies LDS to
+ * LDS, 16-byte drains to the slab) instead of store / fence / load through global memory: 9.8 ms for one
+ * member and, with only two waves per CU, 77.6 instead of 12.5 ms for 4 096 members.
  */
 #include "la_dev.h"
 
@@ -75,14 +75,6 @@ __device__ __forceinline__ uint32_t br_take(bitreader &B, int n)
 	return v;
 }
 
-__device__ __constant__ uint16_t c_len_base[29] = { 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31,
-	35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258 };
-__device__ __constant__ uint8_t c_len_extra[29] = { 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2,
-	3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0 };
-__device__ __constant__ uint16_t c_dist_base[30] = { 1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193,
-	257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577 };
-__device__ __constant__ uint8_t c_dist_extra[30] = { 0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6,
-	7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13 };
 __device__ __constant__ uint8_t c_clc_order[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
 
 __device__ __forceinline__ uint32_t bitrev(uint32_t v, int n) { return __builtin_bitreverse32(v) >> (32 - n); }
@@ -204,7 +196,7 @@ __device__ __forceinline__ void out_flush(out_state &O, int lane)
 }
 
 /* returns LA_ST_OK, LA_ST_GZ_DATA, LA_ST_GZ_TRUNCATED or LA_ST_GZ_OUT_FULL */
-__device__ uint32_t inflate_codes(bitreader &B, out_state &O, const inf_tables *T, bool fixed,
+__device__ __forceinline__ uint32_t inflate_codes(bitreader &B, out_state &O, const inf_tables *T, bool fixed,
     const uint16_t *fx_ll_fast, int lane)
 {
 	(void)fixed; (void)fx_ll_fast;
@@ -225,15 +217,17 @@ __device__ uint32_t inflate_codes(bitreader &B, out_state &O, const inf_tables *
 			return LA_ST_OK;
 		sym -= 257;
 		if (sym >= 29) return LA_ST_GZ_DATA;
-		int xb = c_len_extra[sym];
+		/* base value and extra bits by arithmetic (RFC 1951 3.2.5), as in la_inflate_lanes.hip: a
+		 * constant-table load is a scalar memory round trip in the middle of the serial chain */
+		int xb = sym < 8 ? 0 : sym == 28 ? 0 : (sym - 4) >> 2;
 		if (!br_need(B, xb, lane)) return LA_ST_GZ_TRUNCATED;
-		uint32_t length = c_len_base[sym] + br_take(B, xb);
+		uint32_t length = (sym < 8 ? 3u + (uint32_t)sym : sym == 28 ? 258u : ((4u + ((uint32_t)sym & 3u)) << xb) + 3u) + br_take(B, xb);
 		int ds = huff_decode(B, T->d_fast, D_FAST_BITS, T->d_count, T->d_symbol, T->d_maxlen, lane);
 		if (ds == -1) return LA_ST_GZ_TRUNCATED;
 		if (ds < 0 || ds >= 30) return LA_ST_GZ_DATA;
-		xb = c_dist_extra[ds];
+		xb = ds < 4 ? 0 : (ds >> 1) - 1;
 		if (!br_need(B, xb, lane)) return LA_ST_GZ_TRUNCATED;
-		uint32_t dist = c_dist_base[ds] + br_take(B, xb);
+		uint32_t dist = (ds < 4 ? (uint32_t)ds + 1u : ((2u + ((uint32_t)ds & 1u)) << xb) + 1u) + br_take(B, xb);
 		out_flush(O, lane);
 		if (dist > O.op) return LA_ST_GZ_DATA;
 		if (O.op + length > O.cap) return LA_ST_GZ_OUT_FULL;
@@ -243,9 +237,12 @@ __device__ uint32_t inflate_codes(bitreader &B, out_state &O, const inf_tables *
 			wave_mem_fence();
 			O.visible = O.op;
 		}
-		for (uint32_t j = (uint32_t)lane; j < length; j += LA_WAVE) {
-			uint32_t k = (dist < length) ? (j % dist) : j;
-			O.d[O.op + j] = O.d[O.op - dist + k];
+		if (dist >= length) {	/* (wave-uniform) no overlap: no division */
+			for (uint32_t j = (uint32_t)lane; j < length; j += LA_WAVE)
+				O.d[O.op + j] = O.d[O.op - dist + j];
+		} else {
+			for (uint32_t j = (uint32_t)lane; j < length; j += LA_WAVE)
+				O.d[O.op + j] = O.d[O.op - dist + j % dist];
 		}
 		O.op += length;
 	}
