@@ -21,7 +21,11 @@
  * because inflate_codes() was an out-of-line function taking them by reference (scratch_load /
  * scratch_store + s_waitcnt vmcnt(0) on every refill); inlined: 9.1.  Length / distance bases by
  * arithmetic instead of constant-table loads and no division for non-overlapping copies: see
- * DESIGN.md §5.  Tried and not kept: the output in a 64 KiB LDS ring per wave (match copies LDS to
+ * DESIGN.md §5.  What is left (ISA of this build): the chain state (bit buffer, bit count, byte cursor,
+ * the decoded symbol) still sits in VGPRs and every uniform `if` is an exec-mask sequence (about 900
+ * s_and_saveexec in the kernel against a dozen s_cbranch_scc): the compiler's uniformity analysis loses
+ * the state somewhere; readfirstlane on the member record, on the slow-path LDS loads and on maxlen did
+ * not bring it back.  Finding that source should give the next factor.  Tried and not kept: the output in a 64 KiB LDS ring per wave (match copies LDS to
  * LDS, 16-byte drains to the slab) instead of store / fence / load through global memory: 9.8 ms for one
  * member and, with only two waves per CU, 77.6 instead of 12.5 ms for 4 096 members.
  */
