@@ -25,7 +25,10 @@
  * the decoded symbol) still sits in VGPRs and every uniform `if` is an exec-mask sequence (about 900
  * s_and_saveexec in the kernel against a dozen s_cbranch_scc): the compiler's uniformity analysis loses
  * the state somewhere; readfirstlane on the member record, on the slow-path LDS loads and on maxlen did
- * not bring it back.  Finding that source should give the next factor.  Tried and not kept: the output in a 64 KiB LDS ring per wave (match copies LDS to
+ * not bring it back, and forcing it (readfirstlane on the whole chain state once per symbol: 43 scalar
+ * branches instead of 7) made the kernel 7 % slower -- so the exec-mask form is not what the ~1 800
+ * cycles per symbol are made of either; table builds per block (huff_build is out of line and keeps
+ * its counters in scratch) and the per-symbol latencies are next to stamp.  Tried and not kept: the output in a 64 KiB LDS ring per wave (match copies LDS to
  * LDS, 16-byte drains to the slab) instead of store / fence / load through global memory: 9.8 ms for one
  * member and, with only two waves per CU, 77.6 instead of 12.5 ms for 4 096 members.
  */
