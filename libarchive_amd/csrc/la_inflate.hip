@@ -27,8 +27,8 @@
  * the state somewhere; readfirstlane on the member record, on the slow-path LDS loads and on maxlen did
  * not bring it back, and forcing it (readfirstlane on the whole chain state once per symbol: 43 scalar
  * branches instead of 7) made the kernel 7 % slower -- so the exec-mask form is not what the ~1 800
- * cycles per symbol are made of either; table builds per block (huff_build is out of line and keeps
- * its counters in scratch) and the per-symbol latencies are next to stamp.  Tried and not kept: the output in a 64 KiB LDS ring per wave (match copies LDS to
+ * cycles per symbol are made of either, and neither are the table builds (huff_build inlined, no scratch
+ * left: 9.08 against 9.16 ms).  The per-symbol latencies need stamping next.  Tried and not kept: the output in a 64 KiB LDS ring per wave (match copies LDS to
  * LDS, 16-byte drains to the slab) instead of store / fence / load through global memory: 9.8 ms for one
  * member and, with only two waves per CU, 77.6 instead of 12.5 ms for 4 096 members.
  */
