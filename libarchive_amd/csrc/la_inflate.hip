@@ -28,11 +28,41 @@
  * not bring it back, and forcing it (readfirstlane on the whole chain state once per symbol: 43 scalar
  * branches instead of 7) made the kernel 7 % slower -- so the exec-mask form is not what the ~1 800
  * cycles per symbol are made of either, and neither are the table builds (huff_build inlined, no scratch
- * left: 9.08 against 9.16 ms).  The per-symbol latencies need stamping next.  Tried and not kept: the output in a 64 KiB LDS ring per wave (match copies LDS to
+ * left: 9.08 against 9.16 ms).  Cycle counters in the diagnostic build (tools/exp_inflate_stamps.py, zlib -6
+ * members of the bench stream): 24 216 symbols per 64 KiB member of which 2 251 matches, 930 cycles per
+ * symbol; literal/length decode with refill 357 per symbol (38 %), literal bookkeeping 244 per symbol (26 %),
+ * length + distance decode 1 074 per match (11 %), flush + copy 648 per match (6.5 %), block headers and
+ * table builds 18 %.  Nine symbols in ten are literals at ~600 cycles each: two literals per table look
+ * (pair table) and a chain that really lives in SGPRs are what to build next.  Tried and not kept: the output in a 64 KiB LDS ring per wave (match copies LDS to
  * LDS, 16-byte drains to the slab) instead of store / fence / load through global memory: 9.8 ms for one
  * member and, with only two waves per CU, 77.6 instead of 12.5 ms for 4 096 members.
  */
 #include "la_dev.h"
+
+/* Diagnostic build only (make diag, -DLA_DIAG): per-member cycle totals of the symbol loop's parts go to a
+ * buffer of their own (8 x u64 per member); no output value depends on them. */
+#ifdef LA_DIAG
+__device__ unsigned long long *la_inf_diag;
+extern "C" int la_diag_set_inflate_stamps(void *d_buf)
+{
+	unsigned long long *p = (unsigned long long *)d_buf;
+	return (int)hipMemcpyToSymbol(HIP_SYMBOL(la_inf_diag), &p, sizeof(p));
+}
+struct inf_diag { unsigned long long t, acc[8]; };
+#define DIAG_DECL      inf_diag DG = {}
+#define DIAG_ARG       , inf_diag &DG
+#define DIAG_PASS      , DG
+#define DIAG_T0()      (DG.t = __builtin_readcyclecounter())
+#define DIAG_ACC(k)    do { unsigned long long n_ = __builtin_readcyclecounter(); DG.acc[k] += n_ - DG.t; DG.t = n_; } while (0)
+#define DIAG_CNT(k)    (DG.acc[k] += 1)
+#else
+#define DIAG_DECL      do { } while (0)
+#define DIAG_ARG
+#define DIAG_PASS
+#define DIAG_T0()      do { } while (0)
+#define DIAG_ACC(k)    do { } while (0)
+#define DIAG_CNT(k)    do { } while (0)
+#endif
 
 #define INF_WAVES_PER_WG 4
 #define LL_FAST_BITS 10
@@ -204,11 +234,13 @@ __device__ __forceinline__ void out_flush(out_state &O, int lane)
 
 /* returns LA_ST_OK, LA_ST_GZ_DATA, LA_ST_GZ_TRUNCATED or LA_ST_GZ_OUT_FULL */
 __device__ __forceinline__ uint32_t inflate_codes(bitreader &B, out_state &O, const inf_tables *T, bool fixed,
-    const uint16_t *fx_ll_fast, int lane)
+    const uint16_t *fx_ll_fast, int lane DIAG_ARG)
 {
 	(void)fixed; (void)fx_ll_fast;
 	for (;;) {
+		DIAG_T0();
 		int sym = huff_decode(B, T->ll_fast, LL_FAST_BITS, T->ll_count, T->ll_symbol, T->ll_maxlen, lane);
+		DIAG_ACC(0); DIAG_CNT(6);
 		if (sym == -1) return LA_ST_GZ_TRUNCATED;
 		if (sym < 0) return LA_ST_GZ_DATA;
 		if (sym < 256) {
@@ -218,6 +250,7 @@ __device__ __forceinline__ uint32_t inflate_codes(bitreader &B, out_state &O, co
 			O.npend++;
 			if (O.npend == LA_WAVE)
 				out_flush(O, lane);
+			DIAG_ACC(1);
 			continue;
 		}
 		if (sym == 256)
@@ -235,6 +268,7 @@ __device__ __forceinline__ uint32_t inflate_codes(bitreader &B, out_state &O, co
 		xb = ds < 4 ? 0 : (ds >> 1) - 1;
 		if (!br_need(B, xb, lane)) return LA_ST_GZ_TRUNCATED;
 		uint32_t dist = (ds < 4 ? (uint32_t)ds + 1u : ((2u + ((uint32_t)ds & 1u)) << xb) + 1u) + br_take(B, xb);
+		DIAG_ACC(2); DIAG_CNT(7);
 		out_flush(O, lane);
 		if (dist > O.op) return LA_ST_GZ_DATA;
 		if (O.op + length > O.cap) return LA_ST_GZ_OUT_FULL;
@@ -252,6 +286,7 @@ __device__ __forceinline__ uint32_t inflate_codes(bitreader &B, out_state &O, co
 				O.d[O.op + j] = O.d[O.op - dist + j % dist];
 		}
 		O.op += length;
+		DIAG_ACC(3);
 	}
 }
 
@@ -268,6 +303,10 @@ __global__ __launch_bounds__(64 * INF_WAVES_PER_WG) void inflate_kernel(const ui
 	inf_tables *T = &tabs[wv];
 	const la_gz_member m = members[mi];
 	uint32_t status = LA_ST_OK;
+	DIAG_DECL;
+#ifdef LA_DIAG
+	const unsigned long long dg_start = __builtin_readcyclecounter();
+#endif
 	bitreader B;
 	B.hold = 0; B.bits = 0;
 	B.ip = src + m.src_off;
@@ -316,7 +355,7 @@ __global__ __launch_bounds__(64 * INF_WAVES_PER_WG) void inflate_kernel(const ui
 				T->lens[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : i < 288 ? 8 : 5;
 			huff_build(T->lens, 288, T->ll_count, T->ll_symbol, T->ll_fast, LL_FAST_BITS, &T->ll_maxlen, lane);
 			huff_build(T->lens + 288, 32, T->d_count, T->d_symbol, T->d_fast, D_FAST_BITS, &T->d_maxlen, lane);
-			status = inflate_codes(B, O, T, true, nullptr, lane);
+			status = inflate_codes(B, O, T, true, nullptr, lane DIAG_PASS);
 			if (status != LA_ST_OK) break;
 		} else if (type == 2) {
 			if (!br_need(B, 14, lane)) { status = LA_ST_GZ_TRUNCATED; break; }
@@ -393,7 +432,7 @@ __global__ __launch_bounds__(64 * INF_WAVES_PER_WG) void inflate_kernel(const ui
 			e = huff_build(L + nlen, ndist, T->d_count, T->d_symbol, T->d_fast, D_FAST_BITS, &T->d_maxlen, lane);
 			int dm = __builtin_amdgcn_readfirstlane((int)T->d_maxlen);
 			if (e < 0 || (e > 0 && dm > 1)) { status = LA_ST_GZ_DATA; break; }
-			status = inflate_codes(B, O, T, false, nullptr, lane);
+			status = inflate_codes(B, O, T, false, nullptr, lane DIAG_PASS);
 			if (status != LA_ST_OK) break;
 		} else {
 			status = LA_ST_GZ_DATA;
@@ -405,6 +444,13 @@ __global__ __launch_bounds__(64 * INF_WAVES_PER_WG) void inflate_kernel(const ui
 	/* what zlib would have emitted before noticing: whole symbols, stored data bytewise */
 	if (status != LA_ST_GZ_OUT_FULL)
 		out_flush(O, lane);
+#ifdef LA_DIAG
+	if (lane == 0 && la_inf_diag) {
+		for (int k = 0; k < 8; k++)
+			la_inf_diag[(size_t)mi * 8 + k] = DG.acc[k];
+		la_inf_diag[(size_t)mi * 8 + 4] = __builtin_readcyclecounter() - dg_start;	/* whole member */
+	}
+#endif
 	uint32_t consumed = (uint32_t)(B.ip - (src + m.src_off)) - (uint32_t)(B.bits >> 3);
 	if (lane == 0) {
 		la_gz_result r;
