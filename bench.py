@@ -11,8 +11,14 @@ resident in HBM before the timed region; outputs stay in HBM.
 
 Launch:  python bench.py [--gpus N --steps K --warmup W]
          python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
-Independent blocks shard across ranks (each rank owns its own frame range: weak
-scaling, no data-path collective); ranks exchange only their 32-byte batch summary.
+With --gpus N > 1 and no WORLD_SIZE in the environment, bench.py starts the N ranks itself
+(torch.distributed.run as a CHILD process, before anything here has touched a GPU).
+N ranks = ONE stream of N x 16 GiB decoded (BASELINE configs[4] at N = 8), indexed once on the
+host and cut on frame boundaries into N contiguous ranges balanced by C + U
+(libarchive_amd/shard.py); every rank uploads and decodes only its range: weak scaling, no
+data-path collective, ranks exchange only their batch summary.  --gather adds the explicit
+gather of the decoded ranges to rank 0 over RCCL (the "single stream split" mode), timed
+separately and reported beside the sharded number.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
   roofline      -- dominant kernel (lz4 expand): algorithmic bytes C+U per launch divided by
@@ -47,21 +53,35 @@ def parse():
     ap.add_argument("--unique-mib", type=int, default=1024, help="unique decoded MiB generated on the host, tiled on device")
     ap.add_argument("--cpu-sample-mib", type=int, default=1024, help="decoded MiB the CPU baseline decodes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--api-mib", type=int, default=2048, help="decoded MiB of the A-level (la_cat) measurement, 0 = skip")
     ap.add_argument("--general-only", action="store_true", help="force the general expand kernel")
     ap.add_argument("--extra-options", type=int, default=0, help="diagnostic: extra LA_LZ4_OPT_* bits")
+    ap.add_argument("--gather", action="store_true", default=os.environ.get("LA_BENCH_GATHER", "") == "1",
+                    help="N > 1: also time one gather of all decoded ranges to rank 0 (needs about N x 16 GiB free on GPU 0)")
     ap.add_argument("--workload", choices=["lz4", "gzip"], default="lz4",
                     help="lz4 = BASELINE configs[1] (the headline); gzip = configs[2] shape (64 KiB BGZF-style members)")
     return ap.parse_args()
 
 
-def build_tiled_stream(torch, la, S, rank, unique_mib, total_gib, device):
-    """Host: generate + index the unique region.  Device: tile stream and tables."""
+def kernel_source_id():
+    """Identifies the build of the dominant kernel a PMC traffic figure belongs to."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("la_lz4_fast.hip", "la_dev.h"):
+        h.update(open(os.path.join(ROOT, "libarchive_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def build_tiled_stream(torch, la, S, rank, world, unique_mib, total_gib, device):
+    """Host: generate + index the unique region once; the stream is that region tiled
+    (tiles x world times), its index the region's index tiled.  The splitter cuts the WHOLE
+    stream's frame list; this rank materialises only its own byte range on its device."""
     from libarchive_amd import _native as N
+    from libarchive_amd.shard import slice_index, split_stream
     frames_unique = max(1, (unique_mib << 20) // (BPF * BLOCK))
     tiles = max(1, int(round(total_gib * (1 << 30) / (frames_unique * BPF * BLOCK))))
-    first_frame = rank * frames_unique  # every rank decodes its own frame range of the stream
     t0 = time.time()
-    img, plain = S.synth_lz4_stream(SEED, first_frame, frames_unique, BPF, BLOCK,
+    img, plain = S.synth_lz4_stream(SEED, 0, frames_unique, BPF, BLOCK,
                                     nthreads=min(16, os.cpu_count() or 1), want_plain=False)
     t_gen = time.time() - t0
     t0 = time.time()
@@ -69,25 +89,53 @@ def build_tiled_stream(torch, la, S, rank, unique_mib, total_gib, device):
     t_index = time.time() - t0
     assert idx.end_kind == N.LA_END_EOF and len(idx.frames) == frames_unique
     nb, nf, clen = len(idx.blocks), len(idx.frames), int(img.size)
-    # device-side tiling of the stream and of the job tables
-    d_unique = torch.from_numpy(img).to(device)
-    d_src = d_unique.repeat(tiles)
-    del d_unique
-    blocks = np.tile(idx.blocks, tiles)
-    frames = np.tile(idx.frames, tiles)
-    t_of_b = np.repeat(np.arange(tiles, dtype=np.uint64), nb)
-    t_of_f = np.repeat(np.arange(tiles, dtype=np.uint64), nf)
+    # the whole stream's tables (world x tiles copies of the region's)
+    T = tiles * world
+    blocks = np.tile(idx.blocks, T)
+    frames = np.tile(idx.frames, T)
+    t_of_b = np.repeat(np.arange(T, dtype=np.uint64), nb)
+    t_of_f = np.repeat(np.arange(T, dtype=np.uint64), nf)
     blocks["src_off"] += t_of_b * np.uint64(clen)
     frames["desc_off"] += t_of_f * np.uint64(clen)
     frames["first_block"] += (t_of_f * np.uint64(nb)).astype(np.uint32)
-    tiled = N.Lz4Index(blocks, frames, idx.end_kind, clen * tiles, idx.max_out * tiles)
+    whole = N.Lz4Index(blocks, frames, idx.end_kind, clen * T, idx.max_out * T)
+    f_lo, f_hi = split_stream(whole, clen * T, world)[rank]
+    mine, b_lo, b_hi = slice_index(whole, clen * T, f_lo, f_hi)
+    del blocks, frames, whole
+    # this rank's bytes [b_lo, b_hi) of the stream, assembled on the device from the region's image
+    d_unique = torch.from_numpy(img).to(device)
+    parts, pos = [], b_lo
+    while pos < b_hi:
+        o = pos % clen
+        n = min(clen - o, b_hi - pos)
+        parts.append(d_unique[o:o + n])
+        pos += n
+    d_src = torch.cat(parts) if len(parts) != 1 else parts[0].clone()
+    del parts, d_unique
     info = dict(frames_unique=frames_unique, tiles=tiles, gen_s=t_gen, index_s_unique=t_index,
-                unique_compressed=clen, unique_blocks=nb)
-    return img, idx, d_src, tiled, info
+                unique_compressed=clen, unique_blocks=nb, frame_range=(f_lo, f_hi), byte_range=(b_lo, b_hi),
+                first_tile_frame=f_lo % nf)
+    return img, idx, d_src, mine, info
 
 
-def cpu_baseline(S, O, img_unique, idx_unique, sample_mib, budget_s=12.0):
-    """The oracle (port of the reference lz4 filter incl. all XXH32 checks), 1 thread."""
+def _timed_decodes(O, sample, cap, budget_s):
+    reps, dt, t0, out = 0, 0.0, time.time(), None
+    while dt < budget_s:
+        out, res = O.lz4_stream_decode(sample, cap)
+        assert res.rc == 0
+        reps += 1
+        dt = time.time() - t0
+    return reps, dt, out
+
+
+def cpu_baseline(S, O, img_unique, idx_unique, sample_mib, budget_s=8.0):
+    """CPU side of the same run, on a bounded sample of the same stream:
+    (i) the oracle = port of the reference lz4 filter incl. all XXH32 checks, 1 thread (libarchive is
+    single-threaded per archive); (ii) the same framing and checks with the box's own liblz4
+    LZ4_decompress_safe behind it (dlopen) -- what libarchive's filter executes; (iii) N independent
+    replicas of (ii) (or (i) without liblz4) on all host cores, N stated."""
+    import ctypes as C
+    import threading
     nframes = len(idx_unique.frames)
     want = max(1, min(nframes, (sample_mib << 20) // (BPF * BLOCK)))
     end = int(idx_unique.frames["desc_off"][want] - 4) if want < nframes else int(img_unique.size)
@@ -95,15 +143,82 @@ def cpu_baseline(S, O, img_unique, idx_unique, sample_mib, budget_s=12.0):
     cap = want * BPF * BLOCK + 64
     out, res = O.lz4_stream_decode(sample, cap)
     assert res.rc == 0 and len(out) == want * BPF * BLOCK
-    # bounded sample: repeat the same frames until about `budget_s` of CPU work is done
-    reps, dt, t0 = 0, 0.0, time.time()
-    while dt < budget_s:
-        out2, res = O.lz4_stream_decode(sample, cap)
-        reps += 1
-        dt = time.time() - t0
-    return dict(value=round(reps * len(out) / dt / (1 << 20), 1), unit="MiB/s", cores=1, kind="port",
+    mib = len(out) / (1 << 20)
+    reps, dt, _ = _timed_decodes(O, sample, cap, budget_s)
+    line = dict(value=round(reps * mib / dt, 1), unit="MiB/s", cores=1, kind="port",
                 sample="%d x %d MiB decoded (%d frames of the same stream), oracle lz4 filter with block+content XXH32 checks, %.1f s of CPU work"
-                       % (reps, len(out) >> 20, want, dt)), out
+                       % (reps, int(mib), want, dt))
+    variants = []
+    have_liblz4 = False
+    try:
+        lz = C.CDLL("liblz4.so.1")
+        O.lib().orc_set_external_lz4(C.cast(lz.LZ4_decompress_safe, C.c_void_p), C.cast(lz.LZ4_decompress_safe_usingDict, C.c_void_p))
+        have_liblz4 = True
+        out2, res2 = O.lz4_stream_decode(sample, cap)
+        assert res2.rc == 0 and np.array_equal(out2, out)
+        reps, dt, _ = _timed_decodes(O, sample, cap, budget_s * 0.6)
+        variants.append(dict(value=round(reps * mib / dt, 1), unit="MiB/s", cores=1, kind="liblz4",
+                             sample="same sample and framing, blocks decoded by the box's liblz4 %s LZ4_decompress_safe, XXH32 checks by the port, %.1f s"
+                                    % (C.cast(lz.LZ4_versionString, C.CFUNCTYPE(C.c_char_p))().decode(), dt)))
+    except (OSError, AttributeError) as e:
+        variants.append(dict(kind="liblz4", error="not loadable on this box: %s" % e))
+    # all host cores: N independent replicas (threads; the C call releases the GIL), same sample each
+    ncores = os.cpu_count() or 1
+    counts = [0] * ncores
+    stop = time.time() + budget_s * 0.75
+
+    def replica(i):
+        while time.time() < stop:
+            o, r = O.lz4_stream_decode(sample, cap)
+            assert r.rc == 0 and len(o) == len(out)
+            counts[i] += 1
+    t0 = time.time()
+    th = [threading.Thread(target=replica, args=(i,)) for i in range(ncores)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.time() - t0
+    variants.append(dict(value=round(sum(counts) * mib / dt, 1), unit="MiB/s", cores=ncores,
+                         kind="liblz4 replicas" if have_liblz4 else "port replicas",
+                         sample="%d independent replicas of the same decode on all %d host cores, %d decodes of %d MiB in %.1f s"
+                                % (ncores, ncores, sum(counts), int(mib), dt)))
+    if have_liblz4:
+        O.lib().orc_set_external_lz4(None, None)
+    line["variants"] = variants
+    return line, out
+
+
+def api_level(S, args):
+    """A-level: the whole drop-in path as bsdcat drives it -- file in /dev/shm -> read core ->
+    lz4 filter (gather, H2D, device decode, D2H) -> archive_read_data_block -> /dev/null, PCIe both ways,
+    process start and HIP initialisation included.  Runs la_cat as a CHILD process before this process has
+    touched the GPU.  Never `value`."""
+    import subprocess
+    mib = args.api_mib
+    cat = os.path.join(ROOT, "libarchive_amd", "host", "la_cat")
+    if mib <= 0 or not os.path.exists(cat) or not os.path.isdir("/dev/shm"):
+        return None
+    img, _ = S.synth_lz4_stream(SEED, 0, mib, BPF, BLOCK, nthreads=min(16, os.cpu_count() or 1), want_plain=False)
+    path = "/dev/shm/la_bench_%d.lz4" % os.getpid()
+    try:
+        img.tofile(path)
+        res = {}
+        for name, argv in (("bsdcat_10k_blocks", [cat, path]), ("block_size_16m", [cat, "-b", str(16 << 20), path])):
+            best = None
+            for _ in range(2):
+                t0 = time.time()
+                r = subprocess.run(argv, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=300)
+                dt = time.time() - t0
+                if r.returncode != 0:
+                    return dict(error=r.stderr.decode(errors="replace")[-300:])
+                best = dt if best is None else min(best, dt)
+            res[name] = round(mib / best, 1)
+        return dict(unit="MiB/s decoded", program="la_cat (bsdcat shape) over a %d MiB-decoded .lz4 in /dev/shm, best of 2, process start + HIP init + PCIe both ways included" % mib,
+                    compressed_bytes=int(img.size), **res)
+    finally:
+        if os.path.exists(path):
+            os.unlink(path)
 
 
 def _gz_make_member(args):
@@ -119,23 +234,27 @@ def _gz_make_member(args):
 def main_gzip(args):
     """configs[2] shape: concatenated gzip members of 64 KiB with a BGZF-style size subfield,
     CRC32 + ISIZE verified on the device.  Secondary line (the headline is the lz4 workload)."""
-    import multiprocessing as mp
+    # The host side first -- stream synthesis and member compression -- with THREADS (zlib releases
+    # the GIL) and before anything here initialises the GPU: a forked worker of a process that holds an
+    # HSA / profiler state crashes in the profiler's signal handler at pool teardown (round-1 abort under
+    # rocprofv3 --pmc).
+    from concurrent.futures import ThreadPoolExecutor
+    import streams as S
+    uniq_mib = min(args.unique_mib, 256)
+    frames = (uniq_mib << 20) // (BPF * BLOCK)
+    _, plain = S.synth_lz4_stream(SEED, 0, frames, BPF, BLOCK, nthreads=min(16, os.cpu_count() or 1))
+    pieces = [(plain[i:i + BLOCK].tobytes(),) for i in range(0, plain.size, BLOCK)]
+    with ThreadPoolExecutor(min(16, os.cpu_count() or 1)) as pool:
+        members = list(pool.map(_gz_make_member, pieces, chunksize=64))
     import torch
     import libarchive_amd as la
     from libarchive_amd import _native as N
     from libarchive_amd.gzip import GzDevicePlan
-    import streams as S
 
     assert torch.cuda.is_available()
     device = torch.device("cuda", 0)
     ctx = la.GpuContext(0)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    uniq_mib = min(args.unique_mib, 256)
-    frames = (uniq_mib << 20) // (BPF * BLOCK)
-    _, plain = S.synth_lz4_stream(SEED, 0, frames, BPF, BLOCK, nthreads=min(16, os.cpu_count() or 1))
-    pieces = [(plain[i:i + BLOCK].tobytes(),) for i in range(0, plain.size, BLOCK)]
-    with mp.get_context("fork").Pool(min(16, os.cpu_count() or 1)) as pool:
-        members = pool.map(_gz_make_member, pieces, chunksize=64)
     img = np.frombuffer(b"".join(members), dtype=np.uint8)
     idx = la.gz_index(img, at_eof=True)
     assert len(idx.members) == len(pieces) and idx.speculative == 0
@@ -177,6 +296,40 @@ def main_gzip(args):
         assert res.rc == 0 and np.array_equal(out, plain)
         cpu = dict(value=round(reps * plain.size / el / (1 << 20), 1), unit="MiB/s", cores=1, kind="port",
                    sample="%d x %d MiB decoded, oracle gzip filter (inflate + trailer CRC32), %.1f s" % (reps, plain.size >> 20, el))
+        # the box's own zlib behind the product walker's member table: what libarchive's filter executes (gzip.c:479)
+        import threading
+        import zlib
+        raw = img.tobytes()
+        spans = [(int(m["src_off"]), int(m["src_len"])) for m in idx.members]
+
+        def zl_pass():
+            n = 0
+            for o, ln in spans:
+                n += len(zlib.decompressobj(-15).decompress(raw[o:o + ln]))
+            return n
+        assert zl_pass() == plain.size
+        reps, el, t1 = 0, 0.0, time.time()
+        while el < 5.0:
+            zl_pass()
+            reps += 1
+            el = time.time() - t1
+        variants = [dict(value=round(reps * plain.size / el / (1 << 20), 1), unit="MiB/s", cores=1, kind="zlib",
+                         sample="%d x %d MiB, zlib %s inflate per member (no CRC check, like the reference), %.1f s" % (reps, plain.size >> 20, zlib.ZLIB_RUNTIME_VERSION, el))]
+        ncores = os.cpu_count() or 1
+        counts, stop = [0] * ncores, time.time() + 5.0
+
+        def replica(i):
+            while time.time() < stop:
+                zl_pass()
+                counts[i] += 1
+        t1 = time.time()
+        th = [threading.Thread(target=replica, args=(i,)) for i in range(ncores)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        el = time.time() - t1
+        variants.append(dict(value=round(sum(counts) * plain.size / el / (1 << 20), 1), unit="MiB/s", cores=ncores, kind="zlib replicas",
+                             sample="%d independent replicas on all host cores, %d passes of %d MiB in %.1f s" % (ncores, sum(counts), plain.size >> 20, el)))
+        cpu["variants"] = variants
     # deflate decode = entropy decode (inflate_symbols) + LDS-window expand (inflate_expand) + in-place
     # kernel for members the window kernel cannot take (inflate); older single-kernel paths only have the last
     inf_ms = float(sum(np.mean(phase_ms[k]) for k in ("inflate_symbols", "inflate_expand", "inflate") if k in phase_ms))
@@ -199,18 +352,42 @@ def main_gzip(args):
         sys.exit(3)
 
 
+def launch_ranks(args):
+    """--gpus N without a launcher: start N ranks as a child (torch.distributed.run), from a process
+    that has not touched a GPU, and leave with the child's exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
     if args.workload == "gzip":
         return main_gzip(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: launch %d ranks (python bench.py --gpus %d starts them itself)"
+                 % (args.gpus, world, args.gpus, args.gpus))
+    import streams as S
+    api = None
+    if world == 1 and not args.no_cpu_baseline:
+        api = api_level(S, args)      # child process, before this one initialises the GPU
     import torch
     import torch.distributed as dist
     import libarchive_amd as la
     from libarchive_amd import _native as N
     from libarchive_amd.lz4 import Lz4DevicePlan
-    import streams as S
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
@@ -223,7 +400,7 @@ def main():
     ctx = la.GpuContext(local)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 
-    img_u, idx_u, d_src, tiled, info = build_tiled_stream(torch, la, S, rank, args.unique_mib, args.gib, device)
+    img_u, idx_u, d_src, tiled, info = build_tiled_stream(torch, la, S, rank, world, args.unique_mib, args.gib, device)
     plan = Lz4DevicePlan(ctx, d_src, tiled)
     C_bytes = int(d_src.numel())
     U_bytes = int(tiled.max_out)  # every synthetic block decodes to exactly 64 KiB
@@ -252,14 +429,35 @@ def main():
     # ---- verification outside the timed region: checksums-of-everything + oracle sample ----
     sm = plan.summary()
     ok = (int(sm["total_out"]) == U_bytes and int(sm["n_bad_units"]) == 0 and int(sm["n_bad_frames"]) == 0)
+    # the stream is the unique region repeated: the decoded range must repeat with the region's period
     tile_bytes = info["frames_unique"] * BPF * BLOCK
-    out0 = plan.d_dst[:tile_bytes]
-    for t in range(1, info["tiles"]):
-        ok = ok and bool(torch.equal(out0, plan.d_dst[t * tile_bytes:(t + 1) * tile_bytes]))
+    for o in range(0, U_bytes - tile_bytes, tile_bytes):
+        n = min(tile_bytes, U_bytes - tile_bytes - o)
+        ok = ok and bool(torch.equal(plan.d_dst[o:o + n], plan.d_dst[o + tile_bytes:o + tile_bytes + n]))
 
     # the only exchange: per-rank summaries (no decoded bytes move; outputs stay sharded)
     from libarchive_amd.shard import exchange_summaries
     dt_max, U_all, C_all, ok_all = exchange_summaries(dist, device, dt, U_bytes, C_bytes, ok)
+
+    # explicit "single stream split" mode: the decoded ranges gathered to rank 0 over RCCL, timed on its own
+    gather = None
+    if world > 1 and args.gather:
+        from libarchive_amd.shard import gather_ranges_into
+        barrier()
+        t0 = time.perf_counter()
+        buf, slot, sizes = gather_ranges_into(dist, device, plan.d_dst[:U_bytes], root=0)
+        barrier()
+        dt_g = time.perf_counter() - t0
+        if rank == 0:
+            g_ok = all(bool(torch.equal(buf[r * slot:r * slot + min(sizes[r], tile_bytes)][-4096:],
+                                        buf[:min(sizes[r], tile_bytes)][-4096:])) for r in range(world)
+                       if info["first_tile_frame"] == 0 and sizes[r] >= tile_bytes)
+            step_s = dt_max / args.steps
+            gather = {"gather_ms": round(dt_g * 1e3, 2), "bytes_to_root": int(sum(sizes) - sizes[0]),
+                      "GBps_into_root": round((sum(sizes) - sizes[0]) / dt_g / 1e9, 1),
+                      "value_with_gather": round(U_all / (step_s + dt_g) / (1 << 20), 1), "unit": "MiB/s",
+                      "spot_check": bool(g_ok)}
+        del buf
 
     if rank == 0:
         cpu = None
@@ -271,12 +469,18 @@ def main():
             sample_ok = bool(np.array_equal(got, ref_out))
             ok_all = ok_all and sample_ok
         exp_ms = float(np.mean(phase_ms.get("lz4_expand", [float("nan")])))
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tpath) and abs(args.gib - 16.0) < 1e-6 and not args.general_only:
-            # PMC-measured HBM bytes of the expand kernel for this exact workload (separate
-            # rocprofv3 --pmc passes, committed under profiles/), per slice launch like `achieved`
-            traffic = json.load(open(tpath))["lz4_expand_fast_kernel"]["hbm_bytes_per_launch"]
+        # PMC-measured HBM bytes of the expand kernel for this exact workload (separate rocprofv3 --pmc
+        # passes, tools/exp_traffic.sh, committed under profiles/), per slice launch like `achieved`.
+        # The file names the kernel source it was measured on: a stale file is refused, not quoted.
+        traffic, traffic_note = None, None
+        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+        if os.path.exists(tpath) and abs(args.gib - 16.0) < 1e-6 and not args.general_only and not args.extra_options:
+            rec = json.load(open(tpath))
+            if rec.get("kernel_source_sha16") == kernel_source_id():
+                traffic = rec["lz4_expand_fast_kernel"]["hbm_bytes_per_launch"]
+            else:
+                traffic_note = "profiles/r02_traffic.json was measured on another build of the kernel (%s, now %s): not quoted" % (
+                    rec.get("kernel_source_sha16"), kernel_source_id())
         nl = 4 if (plan.n_blocks >= 32768 and not args.general_only) else 1   # slice launches of the expand kernel per step
         # per-launch algorithmic bytes / per-launch duration (the slices are equal, so this is the ratio of the sums)
         achieved = (C_bytes + U_bytes) / (exp_ms * 1e-3) / 1e9
@@ -301,7 +505,9 @@ def main():
                 "decoded_bytes_per_gpu": U_bytes,
                 "unique_region_mib": args.unique_mib,
                 "tiles": info["tiles"],
-                "parallelism": "blocks sharded over %d GPU(s), outputs stay sharded" % world,
+                "parallelism": "ONE stream of %d x %.0f GiB cut on frame boundaries into %d ranges balanced by C+U, one range per GPU, outputs stay sharded"
+                               % (world, args.gib, world),
+                "rank0_frame_range": list(info["frame_range"]),
                 "expand_kernel": "general" if args.general_only else "auto",
                 "host_index_ms_per_gib_compressed": round(info["index_s_unique"] * 1e3 / (info["unique_compressed"] / (1 << 30)), 2),
             },
@@ -318,10 +524,13 @@ def main():
                 "traffic": traffic,
                 "launches_per_step": nl,
                 "algorithmic_bytes": (C_bytes + U_bytes) // nl,   # per launch, like traffic and achieved
+                "traffic_note": traffic_note,
                 "launch_ms": round(exp_ms / nl, 4),
                 "whole_step_frac": round((C_bytes + U_bytes) / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             },
             "cpu_baseline": cpu,
+            "api_level": api,
+            "gather_mode": gather,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

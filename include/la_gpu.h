@@ -170,6 +170,10 @@ typedef struct la_batch_summary {
 #define LA_LZ4_OPT_PARSE_V1     4u	/* first-generation parse: block checksums and token walk as two kernels
 					 * reading global memory per lane (kept as a cross-check of the staged one) */
 
+#define LA_LZ4_OPT_EXPAND_QUEUE 8u	/* second implementation of the LDS-window expand step (la_lz4_fastq.hip: byte-validity
+					 * bitmap, shared ready queue, aligned LDS copies); same results, kept as a cross-check
+					 * and for blocks of long overlapping matches */
+
 typedef struct la_lz4_batch {
 	const uint8_t      *d_src;	/* compressed image (or batch window) in HBM */
 	uint64_t            src_bytes;

@@ -341,6 +341,7 @@ int la_gpu_lz4_decode(la_gpu_ctx *c, const la_lz4_batch *bt)
 		return LA_ERR_ARG;
 	const bool fast = !(bt->options & LA_LZ4_OPT_GENERAL_ONLY);
 	const bool verify = !(bt->options & LA_LZ4_OPT_NO_VERIFY);
+	const bool queue = (bt->options & LA_LZ4_OPT_EXPAND_QUEUE) != 0;
 	lz4_ws w;
 	lz4_ws_layout(&w, NULL, bt->n_blocks, bt->src_bytes, fast);
 	if (w.total > c->ws_bytes) {
@@ -408,7 +409,7 @@ int la_gpu_lz4_decode(la_gpu_ctx *c, const la_lz4_batch *bt)
 		/* eligible blocks with more sequences than one LDS segment: classified on the device,
 		 * shared out over a small grid (a no-op launch when there are none) */
 		h = prof_open(c, "lz4_expand_big", sx);
-		la_launch_lz4_expand_fast_big(sx, bt->d_src, bt->src_bytes, bt->d_blocks, n, bt->d_dst, bt->dst_cap,
+		(queue ? la_launch_lz4_expand_queue_big : la_launch_lz4_expand_fast_big)(sx, bt->d_src, bt->src_bytes, bt->d_blocks, n, bt->d_dst, bt->dst_cap,
 		    bt->d_dst_off, bt->d_out_len, bt->d_block_status, w.nseq, w.table, w.table_off, w.big);
 		prof_close(c, h, sx);
 	}
@@ -419,7 +420,7 @@ int la_gpu_lz4_decode(la_gpu_ctx *c, const la_lz4_batch *bt)
 		const uint32_t first = (uint32_t)((uint64_t)n * i / nsl), last = (uint32_t)((uint64_t)n * (i + 1) / nsl);
 		if (fast) {
 			h = prof_open(c, "lz4_expand", sx);
-			la_launch_lz4_expand_fast(sx, bt->d_src, bt->src_bytes, bt->d_blocks + first, last - first, bt->d_dst,
+			(queue ? la_launch_lz4_expand_queue : la_launch_lz4_expand_fast)(sx, bt->d_src, bt->src_bytes, bt->d_blocks + first, last - first, bt->d_dst,
 			    bt->dst_cap, bt->d_dst_off + first, bt->d_out_len + first, bt->d_block_status + first,
 			    w.nseq + first, w.table, w.table_off + first);
 			prof_close(c, h, sx);

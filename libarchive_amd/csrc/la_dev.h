@@ -362,6 +362,17 @@ void la_launch_lz4_expand_fast_big(hipStream_t s, const uint8_t *d_src, uint64_t
     const uint32_t *d_nseq, const la_lz4_seq *d_table, const uint64_t *d_table_off,
     uint32_t *d_big /* n + 1 words */);
 
+/* la_lz4_fastq.hip: the same contract as the two launches above, queue generation */
+void la_launch_lz4_expand_queue(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
+    const la_lz4_block *d_blocks, uint32_t n, uint8_t *d_dst, uint64_t dst_cap,
+    const uint64_t *d_dst_off, const uint32_t *d_out_len, uint32_t *d_status,
+    const uint32_t *d_nseq, const la_lz4_seq *d_table, const uint64_t *d_table_off);
+void la_launch_lz4_expand_queue_big(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
+    const la_lz4_block *d_blocks, uint32_t n, uint8_t *d_dst, uint64_t dst_cap,
+    const uint64_t *d_dst_off, const uint32_t *d_out_len, uint32_t *d_status,
+    const uint32_t *d_nseq, const la_lz4_seq *d_table, const uint64_t *d_table_off,
+    uint32_t *d_big /* n + 1 words */);
+
 /* la_inflate.hip */
 void la_launch_inflate(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
     const la_gz_member *d_members, uint32_t n, uint8_t *d_dst, uint64_t dst_cap, la_gz_result *d_results);

@@ -229,6 +229,15 @@ __global__ __launch_bounds__(FAST_THREADS, FAST_MIN_WAVES) void lz4_expand_fast_
 	uint32_t prev_end[MAXSTEPS];
 #pragma unroll
 	for (uint32_t r = 0; r < MAXSTEPS; r++) {
+		ent[r] = 0;
+		prev_end[r] = 0;
+	}
+	/* (slot r holds sequences r * FAST_THREADS and up: slots beyond the segment's last sequence
+	 * are skipped wave-uniformly in every pass below -- the kernel is bound by instruction issue) */
+#pragma unroll
+	for (uint32_t r = 0; r < MAXSTEPS; r++) {
+		if (r * FAST_THREADS >= ns)
+			break;
 		const uint32_t k = fast_seq_index(r, wave, lane);
 		ent[r] = k < ns ? seq_load(tab, k) : 0;
 		const seq_t pv = ((k > 0 || kb > 0) && k < ns) ? seq_load(tab_all, kb + k - 1) : 0;
@@ -245,6 +254,8 @@ __global__ __launch_bounds__(FAST_THREADS, FAST_MIN_WAVES) void lz4_expand_fast_
 	/* chunk_first[c] = first sequence whose literals end beyond payload offset 32c */
 #pragma unroll
 	for (uint32_t r = 0; r < MAXSTEPS; r++) {
+		if (r * FAST_THREADS >= ns)
+			break;
 		const uint32_t k = fast_seq_index(r, wave, lane);
 		if (k < ns) {
 			const uint32_t le = SEQ_LIT_SRC(ent[r]) + SEQ_LIT_LEN(ent[r]);
@@ -362,6 +373,8 @@ __global__ __launch_bounds__(FAST_THREADS, FAST_MIN_WAVES) void lz4_expand_fast_
 	for (uint32_t bit = MAXSEQ / 2; bit; bit >>= 1) {
 #pragma unroll
 		for (uint32_t r = 0; r < MAXSTEPS; r++) {
+			if (r * FAST_THREADS >= ns)
+				break;
 			/* largest idx < k with dstpos[idx] <= s0 */
 			const uint32_t k = fast_seq_index(r, wave, lane);
 			const uint32_t s0 = SEQ_DST(ent[r]) + SEQ_LIT_LEN(ent[r]) - SEQ_OFF(ent[r]);
@@ -378,6 +391,9 @@ __global__ __launch_bounds__(FAST_THREADS, FAST_MIN_WAVES) void lz4_expand_fast_
 	uint32_t qlh[MAXSTEPS];	/* last sequence under the source range | last source byte << 16; ~0: none */
 #pragma unroll
 	for (uint32_t r = 0; r < MAXSTEPS; r++) {
+		qlh[r] = 0xFFFFFFFFu;
+		if (r * FAST_THREADS >= ns)
+			continue;
 		const uint32_t k = fast_seq_index(r, wave, lane);
 		const uint32_t d = SEQ_DST(ent[r]), mdst = d + SEQ_LIT_LEN(ent[r]), off = SEQ_OFF(ent[r]);
 		const uint32_t s0 = mdst - off;

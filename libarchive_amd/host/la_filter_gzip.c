@@ -277,8 +277,11 @@ static int gzip_run_batch(struct archive_read_filter *self, struct gzip_private 
 		/* The deflate stream ran into the end of its span although more input exists:
 		 * the boundary (a 1f 8b 08 guess, or a wrong BGZF size) was not the member's
 		 * end.  Decode this member again with the span extended past it. */
-		if (r->status == LA_ST_GZ_TRUNCATED &&
-		    (m->src_off + m->src_len < st->stage_len || !st->upstream_eof)) {
+		if ((r->status == LA_ST_GZ_TRUNCATED &&
+		    (m->src_off + m->src_len < st->stage_len || !st->upstream_eof)) ||
+		    /* ... or it ended with fewer than 8 bytes left in a span that a BGZF size field or a
+		     * boundary guess cut short while the window holds more bytes: same cure */
+		    (r->status == LA_ST_GZ_NO_TRAILER && m->src_off + m->src_len < st->stage_len)) {
 			*used = (size_t)member_start;
 			st->hint_skip = (i == 0 ? prev_skip : 0) + 1;
 			st->hint_cap = i == 0 ? prev_cap : 0;
@@ -322,6 +325,14 @@ static int gzip_run_batch(struct archive_read_filter *self, struct gzip_private 
 				contiguous = 0;
 			take = i + 1;
 			total += r->out_len;
+			if (h->bgzf_size && (uint64_t)r->consumed + 8 < m->src_len) {
+				/* the member ended before the place its BGZF size field points at: the field is
+				 * only a hint (the reference never reads FEXTRA, gzip.c:185-199) and it was wrong.
+				 * The stream goes on right behind this member's trailer: index again from there. */
+				*used = (size_t)(m->src_off + (uint64_t)r->consumed + 8);
+				stop = 1;
+				break;
+			}
 			if (x->speculative && !h->bgzf_size && (uint64_t)r->consumed + 8 < m->src_len) {
 				const uint64_t p = m->src_off + (uint64_t)r->consumed + 8;
 				const uint8_t *q = st->stage + p;

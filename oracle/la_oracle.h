@@ -103,6 +103,9 @@ typedef struct {
 
 /* bid values (lz4.c:138-183, gzip.c:244-255); 0 = no bid */
 int orc_lz4_bid(const uint8_t *p, size_t avail);
+/* cpu_baseline only: decode blocks with an external LZ4_decompress_safe / _safe_usingDict (the
+ * box's liblz4) behind the same framing and checksums; NULL, NULL restores the port */
+void orc_set_external_lz4(void *safe, void *using_dict);
 int orc_gzip_bid(const uint8_t *p, size_t avail);
 
 /* Decode a whole .lz4 file image (lz4.c:289-721).  out may be NULL to count only. */

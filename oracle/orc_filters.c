@@ -62,6 +62,26 @@ typedef struct {
 	orc_stream_result *res;
 } lz4st;
 
+/* bench.py's cpu_baseline leg can put the box's own liblz4 (dlopen'ed there) behind the same
+ * framing: that IS what libarchive's filter executes (lz4.c:557-561, :578-584).  NULL = the port. */
+typedef int (*ext_lz4_safe_fn)(const char *, char *, int, int);
+typedef int (*ext_lz4_dict_fn)(const char *, char *, int, int, const char *, int);
+static ext_lz4_safe_fn ext_lz4_safe;
+static ext_lz4_dict_fn ext_lz4_dict;
+void orc_set_external_lz4(void *safe, void *using_dict)
+{
+	ext_lz4_safe = (ext_lz4_safe_fn)safe;
+	ext_lz4_dict = (ext_lz4_dict_fn)using_dict;
+}
+static int lz4_block(const uint8_t *src, int src_len, uint8_t *dst, int dst_cap, const uint8_t *dict, int dict_len)
+{
+	if (!dict && ext_lz4_safe)
+		return ext_lz4_safe((const char *)src, (char *)dst, src_len, dst_cap);
+	if (dict && ext_lz4_dict)
+		return ext_lz4_dict((const char *)src, (char *)dst, src_len, dst_cap, (const char *)dict, dict_len);
+	return orc_lz4_block_decode(src, src_len, dst, dst_cap, dict, dict_len);
+}
+
 static int lz4_fail(lz4st *s, const char *msg)
 {
 	snprintf(s->res->errmsg, sizeof(s->res->errmsg), "%s", msg);
@@ -157,7 +177,7 @@ static long lz4_data_block(lz4st *s, const uint8_t **p)
 	int n;
 	size_t prefix = 0;
 	if (s->indep) {
-		n = orc_lz4_block_decode(rb + 4, (int)csize, s->blk, s->bmax, NULL, 0);
+		n = lz4_block(rb + 4, (int)csize, s->blk, s->bmax, NULL, 0);
 	} else {
 		prefix = 65536;
 		if (s->decoded_size) {
@@ -167,7 +187,7 @@ static long lz4_data_block(lz4st *s, const uint8_t **p)
 			} else
 				memmove(s->blk, s->blk + s->decoded_size, prefix);
 		}
-		n = orc_lz4_block_decode(rb + 4, (int)csize, s->blk + prefix, s->bmax, s->blk, (int)prefix);
+		n = lz4_block(rb + 4, (int)csize, s->blk + prefix, s->bmax, s->blk, (int)prefix);
 	}
 	if (n < 0)
 		return lz4_fail(s, "lz4 decompression failed");
@@ -230,7 +250,7 @@ static long lz4_legacy_stream(lz4st *s, const uint8_t **p)
 	}
 	if (lz4_left(s) < 4 + (size_t)csize)
 		return lz4_fail(s, "truncated lz4 input");
-	int n = orc_lz4_block_decode(s->src + s->pos + 4, (int)csize, s->blk,
+	int n = lz4_block(s->src + s->pos + 4, (int)csize, s->blk,
 	    (int)(s->blk_size > 0x7fffffff ? 0x7fffffff : s->blk_size), NULL, 0);
 	if (n < 0)
 		return lz4_fail(s, "lz4 decompression failed");

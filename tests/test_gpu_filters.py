@@ -351,3 +351,68 @@ def test_gzip_members_with_unusual_xfl_os_bytes(gpu_ctx, monkeypatch):
             assert out.tobytes() == plain and res.rc == 0
             r = la_api.cat(img + tail, read_size=rnd.choice([None, 4096]))
             assert la_api.as_reference_tuple(r) == (plain, 0, ""), (xfl, osb, every, len(r.data), r.error)
+
+
+def _bgzf_member(data, bsize_delta=0, level=6):
+    """A gzip member with the BGZF-compatible 'BC' size subfield (total member size - 1, u16): the C3
+    stream shape.  bsize_delta != 0 writes a WRONG size into the subfield."""
+    import struct
+    import zlib
+    co = zlib.compressobj(level, zlib.DEFLATED, -15, 9)
+    body = co.compress(data) + co.flush()
+    total = 18 + len(body) + 8
+    hdr = (b"\x1f\x8b\x08\x04" + b"\0\0\0\0" + b"\x00\x03" + struct.pack("<H", 6) + b"BC" +
+           struct.pack("<HH", 2, (total - 1 + bsize_delta) & 0xFFFF))
+    return hdr + body + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data))
+
+
+def test_gzip_bgzf_indexed_members_through_the_filter(gpu_ctx, monkeypatch):
+    """C3's member shape driven through the gzip FILTER (bid, header parse, indexed boundaries, decode,
+    CRC32 / ISIZE) on the device, against the oracle: correct BSIZE subfields, then members whose
+    subfield lies (too small, too large, pointing past the end) -- the subfield is only a hint, the
+    decode decides where a member ends, exactly as the reference (which ignores FEXTRA, gzip.c:185-199)."""
+    rnd = random.Random(99)
+    words = [rnd.randbytes(rnd.randint(2, 11)) for _ in range(300)]
+    datas = [b"".join(rnd.choice(words) for _ in range(rnd.randint(1, 9000)))[:65280] for _ in range(48)]
+    plain = b"".join(datas)
+    good = b"".join(_bgzf_member(d, level=rnd.choice([1, 6, 9])) for d in datas)
+    for batch in ("1", None):
+        if batch:
+            monkeypatch.setenv("LA_GPU_BATCH_MIB", batch)
+        else:
+            monkeypatch.delenv("LA_GPU_BATCH_MIB", raising=False)
+        ref, _ = oracle_tuple(good, "gzip")
+        assert ref == (plain, 0, "")
+        for rs in (None, 4096):
+            assert la_api.as_reference_tuple(la_api.cat(good, read_size=rs)) == ref
+        # lying subfields on some members
+        for deltas in ((0, -5, 0, 0, 7), (3,), (0, 0, 0, 0, 0, 0, 40000), (-17, 0, 25)):
+            img = b"".join(_bgzf_member(d, bsize_delta=deltas[i % len(deltas)]) for i, d in enumerate(datas))
+            ref, _ = oracle_tuple(img, "gzip")
+            assert ref == (plain, 0, "")
+            assert la_api.as_reference_tuple(la_api.cat(img)) == ref, deltas
+        # damaged / cut streams of indexed members: bytes before the event, rc and message as the oracle
+        for cut in (len(good) - 3, len(good) // 2, 19):
+            ref, _ = oracle_tuple(good[:cut], "gzip")
+            assert la_api.as_reference_tuple(la_api.cat(good[:cut])) == ref, cut
+        bad = bytearray(good)
+        bad[len(good) // 3] ^= 0x5A
+        ref, _ = oracle_tuple(bytes(bad), "gzip")
+        assert la_api.as_reference_tuple(la_api.cat(bytes(bad))) == ref
+
+
+def test_gzip_single_member_across_windows(gpu_ctx, monkeypatch):
+    """ONE member several times the gather window (BASELINE configs[0] shape, small): the window has to
+    grow until the member fits; output, rc and the entry name as the oracle says."""
+    monkeypatch.setenv("LA_GPU_BATCH_MIB", "1")
+    rnd = random.Random(12)
+    words = [rnd.randbytes(rnd.randint(3, 14)) for _ in range(500)]
+    plain = b"".join(rnd.choice(words) for _ in range(700000))[:5 * 1024 * 1024 + 123]
+    img = S.gz_member(plain, name=b"one.bin", mtime=77)
+    assert len(img) > 1024 * 1024        # larger than the 1 MiB gather window
+    ref, _ = oracle_tuple(img, "gzip")
+    assert ref == (plain, 0, "")
+    r = la_api.cat(img, read_size=65536)
+    assert la_api.as_reference_tuple(r) == ref and r.pathname == "one.bin" and r.mtime == 77
+    ref, _ = oracle_tuple(img[:-100000], "gzip")
+    assert la_api.as_reference_tuple(la_api.cat(img[:-100000])) == ref

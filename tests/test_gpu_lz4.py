@@ -24,10 +24,11 @@ def gpu_decode(ctx, image, options=None):
     from libarchive_amd import _native as N
     res = []
     for opt in ((0, N.LA_LZ4_OPT_GENERAL_ONLY, N.LA_LZ4_OPT_PARSE_V1,
-                 N.LA_LZ4_OPT_PARSE_V1 | N.LA_LZ4_OPT_GENERAL_ONLY) if options is None else (options,)):
+                 N.LA_LZ4_OPT_PARSE_V1 | N.LA_LZ4_OPT_GENERAL_ONLY,
+                 N.LA_LZ4_OPT_EXPAND_QUEUE) if options is None else (options,)):
         out, rc, msg, plan = decode_image(ctx, image, options=opt)
         res.append((out.tobytes(), rc, msg))
-    assert all(r == res[0] for r in res), "kernel variants disagree (expand fast/general x parse staged/v1)"
+    assert all(r == res[0] for r in res), "kernel variants disagree (expand fast/general/queue x parse staged/v1)"
     return res[0]
 
 
@@ -188,3 +189,33 @@ def test_mutated_blocks_without_checksums(gpu_ctx):
         img, _ = S.lz4_frame(blocks, flg=0x60)
         ref, res = O.lz4_stream_decode(img, 1 << 22)
         assert gpu_decode(gpu_ctx, img) == (ref.tobytes(), res.rc, res.errmsg.decode()), t
+
+
+def test_one_stream_split_over_ranks(gpu_ctx):
+    """The multi-GPU partition of bench.py on one device: ONE stream, indexed once by the product's host
+    walker, cut by libarchive_amd.shard.split_stream on frame boundaries (balanced by C + U); every
+    "rank" uploads and decodes ONLY its byte range through the device C ABI.  The concatenation of the
+    ranges' outputs is the whole stream's output (what the oracle decodes from the whole image), and
+    every range verifies its own checksums."""
+    import torch
+    import libarchive_amd as la
+    from libarchive_amd.lz4 import Lz4DevicePlan
+    from libarchive_amd.shard import slice_index, split_stream
+    img, plain = S.synth_lz4_stream(77, 0, 37, blocks_per_frame=5, block_size=65536, nthreads=4)
+    ref, res = O.lz4_stream_decode(img, plain.size + 16)
+    assert res.rc == 0 and ref.tobytes() == plain.tobytes()
+    idx = la.lz4_index(img)
+    for world in (1, 2, 3, 8):
+        got = []
+        for lo, hi in split_stream(idx, img.size, world):
+            sub, b_lo, b_hi = slice_index(idx, img.size, lo, hi)
+            if hi == lo:
+                continue
+            d_src = torch.from_numpy(img[b_lo:b_hi].copy()).cuda()
+            plan = Lz4DevicePlan(gpu_ctx, d_src, sub)
+            plan.run()
+            delivered, rc, msg = plan.resolve()
+            sm = plan.summary()
+            assert (rc, msg) == (0, "") and int(sm["n_bad_units"]) == 0 and int(sm["n_bad_frames"]) == 0
+            got.append(plan.d_dst[:delivered].cpu().numpy().tobytes())
+        assert b"".join(got) == plain.tobytes(), world

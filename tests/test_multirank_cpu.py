@@ -1,7 +1,10 @@
-"""N > 1 path on CPU: two gloo ranks shard a synthetic many-frame stream by frame range,
-each decodes ITS range (the oracle stands in for the device here -- this test is about the
-sharding and the summary exchange, not the kernels), summaries are exchanged with the same
-helper bench.py uses, and an explicit gather of decoded ranges reproduces the whole payload."""
+"""N > 1 path on CPU: ONE synthetic many-frame stream is indexed once with the product's host
+walker, cut into per-rank frame ranges balanced by C + U with the product's splitter (the one
+bench.py uses), and every gloo rank takes only ITS byte range of the image.  No GPU exists
+here, so the bytes of a range are decoded by the oracle (checker role only -- the same split
+runs through the device kernels in tests/test_gpu_lz4.py::test_one_stream_split_over_ranks);
+summaries are exchanged with the helper bench.py uses, and an explicit gather of decoded
+ranges must reproduce the whole payload: the union of the ranges is the stream."""
 import os
 import socket
 
@@ -14,7 +17,8 @@ import torch.multiprocessing as mp
 import oracle_lib as O
 import streams as S
 import libarchive_amd as la
-from libarchive_amd.shard import exchange_summaries, gather_ranges, shard_range
+from libarchive_amd.shard import (exchange_summaries, frame_weights, gather_ranges, gather_ranges_into,
+                                  shard_range, slice_index, split_stream)
 
 FRAMES, BPF, BS = 7, 3, 4096
 
@@ -29,18 +33,43 @@ def test_shard_range_covers_everything_once():
             assert max(c for _, c in got) - min(c for _, c in got) <= 1
 
 
+def test_split_stream_cuts_on_frame_boundaries_and_balances():
+    img, _ = S.synth_lz4_stream(5, 0, 40, 2, 4096, nthreads=1)
+    idx = la.lz4_index(img)
+    w, bounds = frame_weights(idx, img.size)
+    assert int(bounds[0]) == 0 and int(bounds[-1]) == img.size and len(w) == 40
+    for world in (1, 2, 3, 8, 40, 41):
+        rs = split_stream(idx, img.size, world)
+        assert rs[0][0] == 0 and rs[-1][1] == 40 and all(a[1] == b[0] for a, b in zip(rs, rs[1:]))
+        loads = [float(w[lo:hi].sum()) for lo, hi in rs]
+        if world <= 8:      # no rank carries more than its share plus one frame
+            assert max(loads) <= float(w.sum()) / world + float(w.max())
+        covered = 0
+        for lo, hi in rs:
+            sub, a, b = slice_index(idx, img.size, lo, hi)
+            fresh = la.lz4_index(img[a:b])          # walking the slice alone gives the same tables
+            assert np.array_equal(fresh.blocks, sub.blocks) and np.array_equal(fresh.frames, sub.frames)
+            covered += b - a
+        assert covered == img.size
+
+
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    first, count = shard_range(FRAMES, world, rank)
-    img, plain = S.synth_lz4_stream(11, first, count, BPF, BS, nthreads=1)
-    idx = la.lz4_index(img)                      # product host walker on this rank's shard
-    out, res = O.lz4_stream_decode(img, plain.size + 16)
-    ok = res.rc == 0 and np.array_equal(out, plain) and len(idx.frames) == count
-    dt, U, C, all_ok = exchange_summaries(dist, torch.device("cpu"), 0.5 + rank, plain.size, img.size, ok)
+    img, plain = S.synth_lz4_stream(11, 0, FRAMES, BPF, BS, nthreads=1)      # the ONE stream
+    idx = la.lz4_index(img)                                                  # indexed once (product walker)
+    f_lo, f_hi = split_stream(idx, img.size, world)[rank]
+    sub, b_lo, b_hi = slice_index(idx, img.size, f_lo, f_hi)
+    mine = img[b_lo:b_hi]                                                    # the only bytes this rank touches
+    want = plain[f_lo * BPF * BS:f_hi * BPF * BS]
+    out, res = O.lz4_stream_decode(mine, want.size + 16)
+    ok = res.rc == 0 and np.array_equal(out, want) and len(sub.frames) == f_hi - f_lo
+    dt, U, C, all_ok = exchange_summaries(dist, torch.device("cpu"), 0.5 + rank, want.size, mine.size, ok)
     whole = gather_ranges(dist, torch.device("cpu"), torch.from_numpy(out.copy()), root=0)
+    buf, slot, sizes = gather_ranges_into(dist, torch.device("cpu"), torch.from_numpy(out.copy()), root=0)
     if rank == 0:
-        q.put((dt, U, C, all_ok, whole.numpy().tobytes()))
+        again = b"".join(buf[r * slot:r * slot + n].numpy().tobytes() for r, n in enumerate(sizes))
+        q.put((dt, U, C, all_ok and again == whole.numpy().tobytes(), whole.numpy().tobytes()))
     dist.barrier()
     dist.destroy_process_group()
 

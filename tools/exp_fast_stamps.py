@@ -30,10 +30,8 @@ for i, nme in enumerate(names):
     d = st[:, i + 1] - st[:, i]
     print("  %-18s mean %8.0f  median %8.0f  share %.1f%%" % (nme, d.mean(), np.median(d), 100 * d.sum() / tot.sum()))
 raw = stamps.cpu().numpy().reshape(nb, 8).astype(np.uint64)
-its = raw[:, 6].astype(np.float64); cyc = raw[:, 7].astype(np.float64)
-print("match phase per block: poll-loop iterations summed over 8 waves x steps: %.0f (%.1f per wave-step of ~4), cycles inside iterations summed: %.0f => %.0f cycles per iteration"
-      % (its.mean(), its.mean() / 32, cyc.mean(), cyc.mean() / its.mean()))
-if os.environ.get("LA_DIAG_L"):
-    # build with -DLA_DIAG_L: slot 6 = after the prepass barrier, slot 7 = table entries of the first literal batch arrived
-    a = st[:, 6] - st[:, 0]; b = st[:, 7] - st[:, 6]; c = st[:, 1] - st[:, 7]
-    print("phase L detail (thread 0): prepass+barrier %.0f, chunk_first + entry loads %.0f, literal stores %.0f" % (a.mean(), b.mean(), c.mean()))
+M40 = np.uint64((1 << 40) - 1)
+scan = (raw[:, 6] & M40).astype(np.float64); rounds = (raw[:, 6] >> np.uint64(40)).astype(np.float64)
+copy = (raw[:, 7] & M40).astype(np.float64); bar = ((raw[:, 7] >> np.uint64(40)) << np.uint64(4)).astype(np.float64)
+print("match phase per block (wave 0's view): rounds %.1f, look+push %.0f cycles (%.0f per round), queue work %.0f (%.0f per round), barrier waits %.0f (%.0f per round)"
+      % (rounds.mean(), scan.mean(), scan.mean() / rounds.mean(), copy.mean(), copy.mean() / rounds.mean(), bar.mean(), bar.mean() / rounds.mean()))
