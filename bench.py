@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--unique-mib", type=int, default=1024, help="unique decoded MiB generated on the host, tiled on device")
     ap.add_argument("--cpu-sample-mib", type=int, default=1024, help="decoded MiB the CPU baseline decodes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--api-mib", type=int, default=2048, help="decoded MiB of the A-level (la_cat) measurement, 0 = skip")
+    ap.add_argument("--api-mib", type=int, default=8192, help="decoded MiB of the A-level (la_cat) measurement, 0 = skip")
     ap.add_argument("--general-only", action="store_true", help="force the general expand kernel")
     ap.add_argument("--extra-options", type=int, default=0, help="diagnostic: extra LA_LZ4_OPT_* bits")
     ap.add_argument("--gather", action="store_true", default=os.environ.get("LA_BENCH_GATHER", "") == "1",
@@ -165,12 +165,15 @@ def cpu_baseline(S, O, img_unique, idx_unique, sample_mib, budget_s=8.0):
     # all host cores: N independent replicas (threads; the C call releases the GIL), same sample each
     ncores = os.cpu_count() or 1
     counts = [0] * ncores
+    rwant = min(want, 64)          # 64 MiB per decode: every core finishes several inside the budget
+    rend = int(idx_unique.frames["desc_off"][rwant] - 4) if rwant < nframes else int(img_unique.size)
+    rsample, rcap, rmib = img_unique[:rend], rwant * BPF * BLOCK + 64, rwant * BPF * BLOCK / (1 << 20)
     stop = time.time() + budget_s * 0.75
 
     def replica(i):
         while time.time() < stop:
-            o, r = O.lz4_stream_decode(sample, cap)
-            assert r.rc == 0 and len(o) == len(out)
+            o, r = O.lz4_stream_decode(rsample, rcap)
+            assert r.rc == 0 and len(o) == rwant * BPF * BLOCK
             counts[i] += 1
     t0 = time.time()
     th = [threading.Thread(target=replica, args=(i,)) for i in range(ncores)]
@@ -179,10 +182,10 @@ def cpu_baseline(S, O, img_unique, idx_unique, sample_mib, budget_s=8.0):
     for t in th:
         t.join()
     dt = time.time() - t0
-    variants.append(dict(value=round(sum(counts) * mib / dt, 1), unit="MiB/s", cores=ncores,
+    variants.append(dict(value=round(sum(counts) * rmib / dt, 1), unit="MiB/s", cores=ncores,
                          kind="liblz4 replicas" if have_liblz4 else "port replicas",
-                         sample="%d independent replicas of the same decode on all %d host cores, %d decodes of %d MiB in %.1f s"
-                                % (ncores, ncores, sum(counts), int(mib), dt)))
+                         sample="%d independent replicas of the same decode on all %d host cores, %d decodes of %d MiB (the sample's first frames) in %.1f s"
+                                % (ncores, ncores, sum(counts), int(rmib), dt)))
     if have_liblz4:
         O.lib().orc_set_external_lz4(None, None)
     line["variants"] = variants
@@ -199,7 +202,7 @@ def api_level(S, args):
     cat = os.path.join(ROOT, "libarchive_amd", "host", "la_cat")
     if mib <= 0 or not os.path.exists(cat) or not os.path.isdir("/dev/shm"):
         return None
-    img, _ = S.synth_lz4_stream(SEED, 0, mib, BPF, BLOCK, nthreads=min(16, os.cpu_count() or 1), want_plain=False)
+    img, _ = S.synth_lz4_stream(SEED, 0, mib, BPF, BLOCK, nthreads=min(64, os.cpu_count() or 1), want_plain=False)
     path = "/dev/shm/la_bench_%d.lz4" % os.getpid()
     try:
         img.tofile(path)

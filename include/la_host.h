@@ -104,6 +104,25 @@ int    la_gz_index_build3(const uint8_t *img, uint64_t len, int at_eof, uint32_t
            uint32_t first_cap, uint32_t flags, la_gz_index *idx);
 void   la_gz_index_free(la_gz_index *idx);
 
+/* ---- hash drop-ins (host/la_hash_dropin.c) ----
+ * The 4-pointer table of libarchive/archive_xxhash.h:37-46 (defined as `__archive_xxhash` when built
+ * inside libarchive with -DLA_IN_LIBARCHIVE) and crc32() with zlib's signature
+ * (libarchive/archive_crc32.h:43-52).  One-buffer XXH32 calls run on the calling thread (a single
+ * XXH32 is one serial chain); la_crc32 sends buffers of 8 MiB and more through la_gpu_crc32_many. */
+struct la_archive_xxhash {
+	unsigned int (*XXH32)(const void *input, unsigned int len, unsigned int seed);
+	void        *(*XXH32_init)(unsigned int seed);			/* malloc'ed, free()-able */
+	int          (*XXH32_update)(void *state, const void *input, unsigned int len);	/* 0 = XXH_OK */
+	unsigned int (*XXH32_digest)(void *state);			/* frees the state */
+};
+#ifdef LA_IN_LIBARCHIVE
+extern const struct la_archive_xxhash __archive_xxhash;
+#else
+extern const struct la_archive_xxhash la_archive_xxhash;
+#endif
+unsigned long la_crc32(unsigned long crc, const void *buf, size_t len);
+unsigned long la_crc32_host(unsigned long crc, const void *buf, size_t len);
+
 /* The reference's error string for a device status word / an end kind */
 const char *la_status_message(uint32_t la_st);
 const char *la_end_message(int end_kind, int is_gzip);

@@ -9,5 +9,5 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python bench.py --no-cpu-baseline > $out/stats.log 2>&1 || exit 1
 cp $out/stats/*/*kernel_stats.csv $out/kernel_stats.csv
 bash tools/exp_traffic.sh $out/traffic > $out/traffic.json 2> $out/traffic.err || exit 1
-timeout -k 10 300 python bench.py --workload gzip --gib 4 > $out/bench_gzip.json 2> $out/bench_gzip.err || exit 1
+timeout -k 10 300 python bench.py --workload gzip --gib 16 > $out/bench_gzip.json 2> $out/bench_gzip.err || exit 1
 echo done
