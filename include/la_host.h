@@ -31,7 +31,10 @@ enum {
 	LA_END_MALFORMED_SKIP,	/* "Malformed lz4 data" (skippable frame without a length, lz4.c:349-353) */
 	LA_END_EMPTY_FRAME,	/* a frame without blocks: its checksum is verified, then the stream ends (SURVEY F11 i) */
 	LA_END_NEED_MORE,	/* window ended inside an item and more input may follow (at_eof == 0) */
-	LA_END_GZ_NO_TRAILER	/* deflate body complete, trailer short: ARCHIVE_FATAL without message (gzip.c:419-421) */
+	LA_END_GZ_NO_TRAILER,	/* deflate body complete, trailer short: ARCHIVE_FATAL without message (gzip.c:419-421) */
+	LA_END_GZ_TOO_LARGE	/* a gzip member of 4 GiB or more (compressed span or decoded size): beyond the 32-bit member
+				 * table of this data plane -- an explicit error, never a wrong byte (the reference streams such
+				 * members; a deployment keeps the reference filter for them) */
 };
 
 typedef struct la_lz4_index {
@@ -61,6 +64,10 @@ typedef struct la_lz4_resume {
 	uint32_t blocks_so_far;	/* blocks of the frame indexed in earlier windows */
 } la_lz4_resume;
 int  la_lz4_index_build2(const uint8_t *img, uint64_t len, int at_eof, la_lz4_resume *rs, la_lz4_index *idx);
+/* out_budget: stop indexing in front of the block that would take the window's decoded bytes (sum of
+ * dst_cap) past it (0 = no bound); the rest of the stream is the next window's */
+int  la_lz4_index_build3(const uint8_t *img, uint64_t len, int at_eof, la_lz4_resume *rs, uint64_t out_budget,
+         la_lz4_index *idx);
 void la_lz4_index_free(la_lz4_index *idx);
 
 /* Bid functions (lz4.c:138-183, gzip.c:244-255) over a peeked buffer */

@@ -35,7 +35,7 @@ LA_LZ4F_CONTENT_SUM, LA_LZ4F_HEADER_SUM, LA_LZ4F_CONT, LA_LZ4F_OPEN, LA_LZ4F_HAS
 LA_LZ4_OPT_GENERAL_ONLY, LA_LZ4_OPT_NO_VERIFY, LA_LZ4_OPT_PARSE_V1, LA_LZ4_OPT_EXPAND_QUEUE = 1, 2, 4, 8
 
 (LA_END_EOF, LA_END_TRUNCATED, LA_END_MALFORMED, LA_END_MALFORMED_SKIP, LA_END_EMPTY_FRAME,
- LA_END_NEED_MORE, LA_END_GZ_NO_TRAILER) = range(7)
+ LA_END_NEED_MORE, LA_END_GZ_NO_TRAILER, LA_END_GZ_TOO_LARGE) = range(8)
 
 
 class NativeLibraryMissing(RuntimeError):

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void lz4_parse_kernel(const uint8_t *__restric
 			do {
 				x = bw_get(B, ip++);
 				length += (int)x;
-				if (ip >= iend - 15)
+				if (ip >= iend - 15 || length > oend)	/* (the sum must not wrap: longer than the output fails below) */
 					break;
 			} while (x == 255);
 			hdr = 9;		/* the offset is not in w any more */
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void lz4_parse_kernel(const uint8_t *__restric
 			while (x == 255) {
 				x = bw_get(B, ip++);
 				length += (int)x;
-				if (ip >= iend - LZ4_LASTLIT + 1) { ok = false; break; }
+				if (ip >= iend - LZ4_LASTLIT + 1 || length > oend) { ok = false; break; }
 			}
 			if (!ok) break;
 		}
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void lz4_parse_kernel(const uint8_t *__restric
 			do {
 				x = bw_get(B, ip++);
 				length += (int)x;
-				if (ip >= iend - 15)
+				if (ip >= iend - 15 || length > oend)	/* (the sum must not wrap: longer than the output fails below) */
 					break;
 			} while (x == 255);
 		}
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void lz4_parse_kernel(const uint8_t *__restric
 			do {
 				x = bw_get(B, ip++);
 				length += (int)x;
-				if (ip >= iend - LZ4_LASTLIT + 1) { ok = false; break; }
+				if (ip >= iend - LZ4_LASTLIT + 1 || length > oend) { ok = false; break; }
 			} while (x == 255);
 			if (!ok) break;
 		}

@@ -249,7 +249,9 @@ __global__ __launch_bounds__(PS_THREADS) void lz4_parse_staged_kernel(const uint
 					do {
 						x = get_byte(p++);
 						length += (int)x;
-						if (p >= iend - 15)
+						/* a run of 0xff extension bytes cannot push the 32-bit sum around (a legacy
+						 * block holds 8 MiB of them): longer than the output means failure below */
+						if (p >= iend - 15 || length > oend)
 							break;
 					} while (x == 255);
 				}
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(PS_THREADS) void lz4_parse_staged_kernel(const uint
 					do {
 						x = get_byte(p++);
 						length += (int)x;
-						if (p >= iend - LZ4_LASTLIT + 1) { fail = true; break; }
+						if (p >= iend - LZ4_LASTLIT + 1 || length > oend) { fail = true; break; }
 					} while (x == 255);
 				}
 				length += 4;

@@ -292,7 +292,15 @@ static int gzip_run_batch(struct archive_read_filter *self, struct gzip_private 
 			/* the ISIZE claim was too small for what the member really holds */
 			*used = (size_t)member_start;
 			uint32_t base = m->dst_cap > prev_cap ? m->dst_cap : prev_cap;
-			st->hint_cap = base < 32768 ? 65536 : (base > 0x7FFFFFFFu ? 0xFFFFFFFFu : base * 2);
+			if (base >= 0x80000000u) {
+				/* the slot cannot grow any further (32-bit positions on the device): say so
+				 * instead of retrying for ever or delivering a wrapped slot */
+				gz_set_fatal(st, la_end_message(LA_END_GZ_TOO_LARGE, 1));
+				cutoff = (total / OUT_BLOCK) * OUT_BLOCK;
+				stop = 1;
+				break;
+			}
+			st->hint_cap = base < 32768 ? 65536 : (base > 0x3FFFFFFFu ? 0x80000000u : base * 2);
 			st->hint_skip = i == 0 ? prev_skip : 0;
 			stop = 1;
 			break;
@@ -386,6 +394,9 @@ static int gzip_run_batch(struct archive_read_filter *self, struct gzip_private 
 			st->eof = 1;
 		else if (x->end_kind == LA_END_TRUNCATED) {
 			gz_set_fatal(st, "truncated gzip input");
+			cutoff = (total / OUT_BLOCK) * OUT_BLOCK;
+		} else if (x->end_kind == LA_END_GZ_TOO_LARGE) {
+			gz_set_fatal(st, la_end_message(LA_END_GZ_TOO_LARGE, 1));
 			cutoff = (total / OUT_BLOCK) * OUT_BLOCK;
 		}
 	}
@@ -514,6 +525,8 @@ static ssize_t gzip_filter_read(struct archive_read_filter *self, const void **p
 			}
 			if (kind == LA_END_TRUNCATED)
 				gz_set_fatal(st, "truncated gzip input");
+			else if (kind == LA_END_GZ_TOO_LARGE)
+				gz_set_fatal(st, la_end_message(LA_END_GZ_TOO_LARGE, 1));
 			else
 				st->eof = 1;
 			continue;

@@ -60,6 +60,7 @@ struct lz4_private {
 	struct lz4_slot slot[2];
 	int cur;
 	size_t batch_bytes, max_batch_bytes;
+	uint64_t out_budget;	/* decoded bytes (sum of block maxima) one window may ask for: bounds d_dst and the pinned slab */
 	la_lz4_resume rs;	/* a frame of independent blocks may span windows: where the walker is */
 	uint8_t *d_carry;	/* 2 x LA_XXH_CARRY_BYTES on the device: content-hash state from window to window */
 	uint8_t *d_hist;	/* 64 KiB on the device: the last block of a window, dictionary of the next one's first
@@ -133,6 +134,8 @@ static int lz4_reader_init(struct archive_read_filter *self)
 	st->batch_bytes = (size_t)(bm && atoi(bm) > 0 ? atoi(bm) : 256) << 20;
 	const char *bmx = getenv("LA_GPU_MAX_BATCH_MIB");
 	st->max_batch_bytes = (size_t)(bmx && atoi(bmx) > 0 ? atoi(bmx) : 2048) << 20;
+	const char *ob = getenv("LA_GPU_OUT_BUDGET_MIB");
+	st->out_budget = (uint64_t)(ob && atoi(ob) > 0 ? atoi(ob) : 4096) << 20;
 	int rc = la_gpu_open(dev ? atoi(dev) : 0, &st->gpu);
 	if (rc != LA_OK) {
 		archive_set_error(&self->archive->archive, ARCHIVE_ERRNO_MISC,
@@ -241,7 +244,7 @@ static int lz4_gather_and_index(struct archive_read_filter *self, struct lz4_pri
 
 		/* 2. frame / block headers (host pointer chase, no payload byte touched) */
 		const la_lz4_resume rs_before = st->rs;
-		if (la_lz4_index_build2(sl->stage, sl->stage_len, st->upstream_eof, &st->rs, &sl->idx) != 0) {
+		if (la_lz4_index_build3(sl->stage, sl->stage_len, st->upstream_eof, &st->rs, st->out_budget, &sl->idx) != 0) {
 			archive_set_error(&self->archive->archive, ENOMEM, "Can't allocate data for lz4 decompression");
 			return ARCHIVE_FATAL;
 		}
@@ -253,7 +256,8 @@ static int lz4_gather_and_index(struct archive_read_filter *self, struct lz4_pri
 			st->batch_bytes *= 2;
 			continue;
 		}
-		if (sl->idx.end_kind == LA_END_NEED_MORE && !st->upstream_eof && st->batch_bytes < st->max_batch_bytes) {
+		if (sl->idx.end_kind == LA_END_NEED_MORE && !st->upstream_eof && st->batch_bytes < st->max_batch_bytes &&
+		    sl->idx.max_out < st->out_budget / 2) {	/* (a window the decoded-bytes budget cut short does not grow) */
 			/* Blocks above 64 KiB are parsed by one lane and expanded by one wave each (about
 			 * 0.2 s per 4 MiB block, however many run side by side): their throughput is the
 			 * number of blocks in flight, so a window that holds only a few of them grows. */

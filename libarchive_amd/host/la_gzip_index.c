@@ -170,6 +170,8 @@ static uint64_t next_candidate(const uint8_t *img, uint64_t len, uint64_t from, 
 	return len;
 }
 
+#define LA_GZ_MAX_SLOT 0x80000000u
+
 int la_gz_index_build2(const uint8_t *img, uint64_t len, int at_eof, uint32_t first_skip,
     uint32_t first_cap, la_gz_index *x)
 {
@@ -234,7 +236,7 @@ int la_gz_index_build3(const uint8_t *img, uint64_t len, int at_eof, uint32_t fi
 		}
 		uint64_t span = next - body;
 		if (span > 0xFFFFFFFFull) {
-			x->end_kind = LA_END_TRUNCATED;	/* > 4 GiB member: beyond the table's u32 fields */
+			x->end_kind = LA_END_GZ_TOO_LARGE;	/* > 4 GiB member: beyond the table's u32 fields */
 			break;
 		}
 		if (push(x) < 0) return -1;
@@ -246,6 +248,7 @@ int la_gz_index_build3(const uint8_t *img, uint64_t len, int at_eof, uint32_t fi
 		/* slot from the ISIZE claim; a deflate stream cannot expand more than ~1032x */
 		uint64_t bound = span * 1032 + 64;
 		if (isize > bound) isize = (uint32_t)(bound > 0xFFFFFFFFull ? 0xFFFFFFFFull : bound);
+		if (isize > LA_GZ_MAX_SLOT) isize = LA_GZ_MAX_SLOT;	/* (32-bit positions in the kernels: op + 258 must not wrap) */
 		if (x->n == 1 && first_cap > isize)
 			isize = first_cap;	/* the decode found the ISIZE claim too small */
 		m->dst_cap = isize;

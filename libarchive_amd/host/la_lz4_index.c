@@ -85,6 +85,17 @@ int la_lz4_index_build(const uint8_t *img, uint64_t len, int at_eof, la_lz4_inde
 
 int la_lz4_index_build2(const uint8_t *img, uint64_t len, int at_eof, la_lz4_resume *rs, la_lz4_index *x)
 {
+	return la_lz4_index_build3(img, len, at_eof, rs, 0, x);
+}
+
+/* out_budget != 0 bounds the window by DECODED bytes too (sum of the blocks' dst_cap): highly
+ * compressible input would otherwise make one window of compressed bytes ask for tens of GiB of
+ * slab (the reference streams with one block buffer, lz4.c:240-263).  The walker stops in front of
+ * the block that would pass the budget -- inside a frame only with a resume record -- and reports
+ * LA_END_NEED_MORE; at least one block is always taken. */
+int la_lz4_index_build3(const uint8_t *img, uint64_t len, int at_eof, la_lz4_resume *rs, uint64_t out_budget,
+    la_lz4_index *x)
+{
 	uint64_t pos = 0;
 	memset(x, 0, sizeof(*x));
 	x->end_kind = LA_END_EOF;
@@ -94,6 +105,10 @@ int la_lz4_index_build2(const uint8_t *img, uint64_t len, int at_eof, la_lz4_res
 	for (;;) {
 		/* lz4.c:328-364: select the next stream */
 		x->consumed = pos;
+		if (out_budget && x->n_blocks > 0 && x->max_out >= out_budget && !resume && !resume_legacy) {
+			x->end_kind = LA_END_NEED_MORE;	/* the window is full by decoded bytes: the next frame waits */
+			goto out;
+		}
 		uint32_t m;
 		if (resume)
 			m = LZ4_MAGIC;
@@ -152,7 +167,7 @@ int la_lz4_index_build2(const uint8_t *img, uint64_t len, int at_eof, la_lz4_res
 			f->first_block = x->n_blocks;
 			f->flags = (cont ? LA_LZ4F_CONT : LA_LZ4F_HEADER_SUM) | (ssum ? (LA_LZ4F_CONTENT_SUM | LA_LZ4F_HASHED) : 0);
 			p += dbytes;
-			int end = -1;
+			int end = -1, budget_stop = 0;
 			for (;;) {
 				if (len - p < 4) { end = LA_END_TRUNCATED; break; }
 				uint32_t w = le32(img + p);
@@ -173,6 +188,9 @@ int la_lz4_index_build2(const uint8_t *img, uint64_t len, int at_eof, la_lz4_res
 				}
 				uint32_t csize = w & 0x7fffffffu;
 				if (len - p < 4ull + csize + bsum) { end = LA_END_TRUNCATED; break; }
+				if (out_budget && rs && x->frames[fi].n_blocks > 0 && x->max_out + bmax > out_budget) {
+					end = LA_END_TRUNCATED; budget_stop = 1; break;	/* this block opens the next window */
+				}
 				la_lz4_block *b = push_block(x);
 				if (!b) return -1;
 				b->src_off = p + 4;
@@ -187,7 +205,7 @@ int la_lz4_index_build2(const uint8_t *img, uint64_t len, int at_eof, la_lz4_res
 				x->frames[fi].n_blocks++;
 			}
 			if (end >= 0) {
-				if (!at_eof && rs) {
+				if ((!at_eof || budget_stop) && rs) {
 					/* the frame goes on in the next window: its complete blocks are decoded
 					 * now, the content hash is carried over */
 					x->frames[fi].flags = (x->frames[fi].flags & ~LA_LZ4F_CONTENT_SUM) | LA_LZ4F_OPEN;
@@ -240,7 +258,7 @@ frame_cut:
 			if (!f) return -1;
 			uint32_t fi = x->n_frames - 1;
 			f->first_block = x->n_blocks;
-			int end = -1;
+			int end = -1, budget_stop = 0;
 			for (;;) {
 				if (len - p < 4) {
 					if (x->frames[fi].n_blocks + blocks_before == 0 || !at_eof)
@@ -251,6 +269,9 @@ frame_cut:
 				if (csize > LEGACY_BOUND)
 					break;	/* not a block: re-read as a magic number (lz4.c:698-701) */
 				if (len - p < 4ull + csize) { end = LA_END_TRUNCATED; break; }
+				if (out_budget && rs && x->frames[fi].n_blocks > 0 && x->max_out + LEGACY_BLOCK > out_budget) {
+					end = LA_END_TRUNCATED; budget_stop = 1; break;
+				}
 				la_lz4_block *b = push_block(x);
 				if (!b) return -1;
 				b->src_off = p + 4;
@@ -263,7 +284,7 @@ frame_cut:
 				x->frames[fi].n_blocks++;
 			}
 			if (end >= 0) {
-				if (!at_eof && rs) {
+				if ((!at_eof || budget_stop) && rs) {
 					/* the complete blocks are decoded now, the frame goes on in the next window */
 					rs->in_frame = 2;
 					rs->blocks_so_far = blocks_before + x->frames[fi].n_blocks;
@@ -331,6 +352,7 @@ const char *la_end_message(int end_kind, int is_gzip)
 	case LA_END_MALFORMED: return "malformed lz4 data";
 	case LA_END_MALFORMED_SKIP: return "Malformed lz4 data";
 	case LA_END_GZ_NO_TRAILER: return "";
+	case LA_END_GZ_TOO_LARGE: return "gzip member too large for the GPU data plane (4 GiB limit)";
 	default: return "";
 	}
 }

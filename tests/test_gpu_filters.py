@@ -416,3 +416,39 @@ def test_gzip_single_member_across_windows(gpu_ctx, monkeypatch):
     assert la_api.as_reference_tuple(r) == ref and r.pathname == "one.bin" and r.mtime == 77
     ref, _ = oracle_tuple(img[:-100000], "gzip")
     assert la_api.as_reference_tuple(la_api.cat(img[:-100000])) == ref
+
+
+def test_lz4_window_bounded_by_decoded_bytes(gpu_ctx, monkeypatch):
+    """Highly compressible input: a window of compressed bytes would decode to far more than a sane slab
+    (a few MiB of zeros ask for GiBs).  LA_GPU_OUT_BUDGET_MIB bounds a window by decoded bytes too: the
+    walker stops in front of the block that would pass it -- also INSIDE a frame (independent blocks with
+    a content checksum carried over, dependent blocks with their history, legacy blocks) -- and the next
+    window goes on there.  The byte stream, rc and message stay the reference's."""
+    import oracle_lib as O
+    import streams as S
+    monkeypatch.setenv("LA_GPU_OUT_BUDGET_MIB", "1")        # 16 blocks of 64 KiB per window
+    rnd = random.Random(5150)
+    zeros = [(bytes(65536), S.lz4_block(S.lz4_compress_block(bytes(65536)), bsum=True)) for _ in range(70)]
+    f1, p1 = S.lz4_frame(zeros, flg=0x74)                   # independent, block + content checksums
+    words = [rnd.randbytes(rnd.randint(2, 9)) for _ in range(50)]
+    chunks = [b"".join(rnd.choice(words) for _ in range(9000))[:rnd.choice([65536, 65536, 1234])] for _ in range(45)]
+    f2, p2 = S.lz4_dependent_frame(chunks)                  # dependent blocks across windows
+    tail, tplain = S.synth_lz4_stream(3, 0, 40, blocks_per_frame=2, block_size=65536, nthreads=2)
+    img = f1 + f2 + tail.tobytes()
+    plain = p1 + p2 + tplain.tobytes()
+    assert len(img) < 6 << 20 and len(plain) > 10 << 20
+    for variant in range(3):
+        m = bytearray(img)
+        if variant == 1:
+            m[len(f1) - 2] ^= 0x40          # the first frame's content checksum is wrong
+        elif variant == 2:
+            m = m[:len(f1) + len(f2) // 2]  # cut inside the dependent frame
+        m = bytes(m)
+        out, res = O.lz4_stream_decode(m, 1 << 27)
+        want = (out.tobytes(), res.rc, res.errmsg.decode())
+        if variant == 0:
+            assert want == (plain, 0, "")
+        r = la_api.cat(m, read_size=rnd.choice([None, 65536]))
+        assert la_api.as_reference_tuple(r) == want, variant
+        if variant == 0:
+            assert len(r.block_sizes) >= 8  # many bounded windows, not one huge slab

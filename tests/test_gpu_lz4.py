@@ -219,3 +219,21 @@ def test_one_stream_split_over_ranks(gpu_ctx):
             assert (rc, msg) == (0, "") and int(sm["n_bad_units"]) == 0 and int(sm["n_bad_frames"]) == 0
             got.append(plan.d_dst[:delivered].cpu().numpy().tobytes())
         assert b"".join(got) == plain.tobytes(), world
+
+
+def test_length_extension_run_cannot_wrap_the_sum(gpu_ctx):
+    """A legacy block at the size bound can carry 8.4 million 0xff extension bytes: 15 + 255 * n passes
+    2^31.  liblz4 (size_t) and the oracle (long) reject the block ("lz4 decompression failed"); a 32-bit
+    sum on the device must not wrap into a small or negative length and accept it."""
+    import struct
+    n_ext = 8421510
+    for lit_run in (False, True):
+        if lit_run:     # literal length 15 + 255 * n_ext
+            payload = bytes([0xF0]) + b"\xff" * n_ext + b"\x07" + b"x" * 8
+        else:           # match length
+            payload = bytes([0x1F]) + b"A" + b"\x01\x00" + b"\xff" * n_ext + b"\x07" + b"tail!"
+        assert len(payload) <= 8421520
+        img = struct.pack("<I", 0x184C2102) + struct.pack("<I", len(payload)) + payload
+        ref, res = O.lz4_stream_decode(img, 1 << 24)
+        assert (ref.tobytes(), res.rc, res.errmsg) == (b"", -30, b"lz4 decompression failed")
+        assert gpu_decode(gpu_ctx, img) == (b"", -30, "lz4 decompression failed")
