@@ -35,6 +35,7 @@ extern "C" {
 
 #define ARCHIVE_FORMAT_RAW   0x90000	/* archive.h */
 #define ARCHIVE_FORMAT_EMPTY 0x60000
+#define ARCHIVE_FORMAT_ZIP        0x50000	/* archive.h:361 */
 #define ARCHIVE_FORMAT_TAR        0x30000	/* archive.h:353-357 */
 #define ARCHIVE_FORMAT_TAR_USTAR  (ARCHIVE_FORMAT_TAR | 1)
 #define ARCHIVE_FORMAT_TAR_PAX_INTERCHANGE (ARCHIVE_FORMAT_TAR | 2)
@@ -56,7 +57,8 @@ int  archive_read_support_filter_none(struct archive *);
 int  archive_read_support_format_raw(struct archive *);
 int  archive_read_support_format_empty(struct archive *);
 int  archive_read_support_format_tar(struct archive *);			/* ustar, old tar, GNU and pax names/sizes; no sparse (la_format_tar.c) */
-int  archive_read_support_format_all(struct archive *);			/* the formats of this slice: tar + empty */
+int  archive_read_support_format_zip(struct archive *);			/* central directory on the host, deflate + CRC32 per entry on the device (la_format_zip.c) */
+int  archive_read_support_format_all(struct archive *);			/* the formats of this slice: tar + zip + empty */
 
 int  archive_read_open(struct archive *, void *client_data, archive_open_callback *,
 	archive_read_callback *, archive_close_callback *);

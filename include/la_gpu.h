@@ -242,6 +242,10 @@ typedef struct la_gz_batch {
 #define LA_GZ_OPT_LANE_KERNEL 4u	/* force the in-place lane-per-member kernel */
 #define LA_GZ_OPT_TWO_PHASE   8u	/* force entropy decode + LDS-window expand (the default from 8192 members up) */
 
+#define LA_GZ_OPT_RAW        16u	/* members are bare raw-deflate streams (ZIP entries, archive_read_support_format_zip.c:2536-2700):
+					 * no gzip trailer follows the body, nothing is compared; status, out_len, consumed and
+					 * the CRC32 of the produced bytes are reported */
+
 int la_gpu_gzip_decode(la_gpu_ctx *ctx, const la_gz_batch *batch);
 
 #ifdef __cplusplus

@@ -536,7 +536,7 @@ int la_gpu_gzip_decode(la_gpu_ctx *c, const la_gz_batch *bt)
 	}
 	h = prof_open(c, "gz_crc32", s);
 	la_launch_gz_verify(s, bt->d_src, bt->src_bytes, bt->d_members, bt->n_members, bt->d_dst,
-	    bt->d_results, !(bt->options & LA_GZ_OPT_NO_VERIFY));
+	    bt->d_results, (bt->options & LA_GZ_OPT_RAW) ? 2 : !(bt->options & LA_GZ_OPT_NO_VERIFY));
 	prof_close(c, h, s);
 	if (bt->d_summary)
 		la_launch_gz_summary(s, bt->d_results, bt->n_members, bt->d_summary);

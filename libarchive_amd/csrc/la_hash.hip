@@ -446,7 +446,9 @@ __global__ __launch_bounds__(256) void gz_verify_kernel(const uint8_t *__restric
 		c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
 		uint32_t st = LA_ST_OK;
 		uint64_t tr = m.src_off + r.consumed;
-		if ((uint64_t)r.consumed + 8 > m.src_len || tr + 8 > src_bytes)
+		if (verify == 2)
+			;	/* raw deflate member (LA_GZ_OPT_RAW): there is no trailer to look at */
+		else if ((uint64_t)r.consumed + 8 > m.src_len || tr + 8 > src_bytes)
 			st = LA_ST_GZ_NO_TRAILER;
 		else if (verify) {
 			if (ld_u32(src + tr) != c)

@@ -515,6 +515,8 @@ int archive_read_support_format_empty(struct archive *_a)
 int archive_read_support_format_all(struct archive *_a)
 {
 	int r = archive_read_support_format_tar(_a);
+	if (r == ARCHIVE_OK)
+		r = archive_read_support_format_zip(_a);
 	if (r != ARCHIVE_OK)
 		return r;
 	return archive_read_support_format_empty(_a);

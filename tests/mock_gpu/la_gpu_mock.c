@@ -163,7 +163,9 @@ int la_gpu_gzip_decode(la_gpu_ctx *c, const la_gz_batch *bt)
 		if (r->status == LA_ST_OK) {
 			r->crc32 = orc_crc32(0, bt->d_dst + m->dst_off, prod);
 			const uint64_t tr = m->src_off + cons;
-			if (cons + 8 > m->src_len || tr + 8 > bt->src_bytes)
+			if (bt->options & LA_GZ_OPT_RAW)
+				;	/* raw deflate member: no trailer */
+			else if (cons + 8 > m->src_len || tr + 8 > bt->src_bytes)
 				r->status = LA_ST_GZ_NO_TRAILER;
 			else if (verify) {
 				const uint8_t *t = bt->d_src + tr;
@@ -181,5 +183,13 @@ int la_gpu_gzip_decode(la_gpu_ctx *c, const la_gz_batch *bt)
 	}
 	if (bt->d_summary)
 		*bt->d_summary = sm;
+	return LA_OK;
+}
+
+int la_gpu_crc32_many(la_gpu_ctx *c, const uint8_t *d_base, const la_hash_job *d_jobs, uint32_t n, uint32_t *d_out)
+{
+	(void)c;
+	for (uint32_t i = 0; i < n; i++)
+		d_out[i] = orc_crc32(d_jobs[i].seed, d_base + d_jobs[i].off, d_jobs[i].len);
 	return LA_OK;
 }

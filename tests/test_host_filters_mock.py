@@ -60,6 +60,13 @@ from test_gpu_tar import (  # noqa: E402,F401
 )
 
 
+from test_gpu_zip import (  # noqa: E402,F401
+    test_reference_zip_fixtures,
+    test_written_archives_many_entries,
+    test_check_values_are_enforced,
+)
+
+
 def test_mock_library_is_not_the_product(gpu_ctx):
     """Guard: the product library must not resolve to the mock, and vice versa."""
     import libarchive_amd as la

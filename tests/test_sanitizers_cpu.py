@@ -34,7 +34,7 @@ def run(img):
     O.lz4_stream_decode(img, 1 << 23); O.gzip_stream_decode(img, 1 << 23)
 
 n = 0
-for f in glob.glob(os.path.join(ROOT, "tests", "golden", "ref_fixtures", "*")):
+for f in [g for g in glob.glob(os.path.join(ROOT, "tests", "golden", "ref_fixtures", "*")) if os.path.isfile(g)]:
     if not f.endswith(".json"):
         run(open(f, "rb").read()); n += 1
 for img, *_ in S.appendix_d_lz4_cases().values():
@@ -97,6 +97,19 @@ for img in (tar, _gz_members(tar), _lz4_frames(tar)):
         la_api.list_entries(m, read_size=rnd.choice([None, 512, 4096]), skip_every=rnd.choice([0, 2]))
         la_api.cat(m, read_size=rnd.choice([None, 1000]))
         n += 2
+# ZIP reader: mutated archives (directory records, local headers, bodies, end record) must fail cleanly
+from test_gpu_zip import _make_zip
+import zipfile
+zimg = _make_zip([("d/", b"", zipfile.ZIP_STORED, None)] +
+                 [("d/f%d" % i, bytes(rnd.getrandbits(8) for _ in range(rnd.choice([0, 5, 900]))) * rnd.choice([1, 40]),
+                   rnd.choice([zipfile.ZIP_STORED, zipfile.ZIP_DEFLATED]), 6) for i in range(12)])
+for m in mutations(zimg, 300):
+    la_api.list_entries(m, read_size=rnd.choice([None, 100, 4096]), skip_every=rnd.choice([0, 3])); n += 1
+cdpos = zimg.find(b"PK\x01\x02")
+for pos in list(range(cdpos, min(cdpos + 60, len(zimg)))) + list(range(len(zimg) - 22, len(zimg))):
+    for v in (0, 1, 0x7f, 0xff):
+        m = bytearray(zimg); m[pos] = v
+        la_api.list_entries(bytes(m)); n += 1
 # header-field fuzz on the plain tar: every byte of the first header in turn takes odd values
 for pos in range(0, 512, 3):
     for v in (0, 0x20, 0x37, 0x38, 0x80, 0xff):
@@ -136,7 +149,7 @@ def test_filters_read_core_and_tar_walker_under_asan_ubsan(tmp_path):
     mock = os.path.join(ROOT, "tests", "mock_gpu")
     orc = os.path.join(ROOT, "oracle")
     srcs = [os.path.join(host, f) for f in ("la_lz4_index.c", "la_gzip_index.c", "la_read_core.c", "la_format_tar.c",
-                                            "la_filter_lz4.c", "la_filter_gzip.c")]
+                                            "la_format_zip.c", "la_hash_dropin.c", "la_filter_lz4.c", "la_filter_gzip.c")]
     srcs += [os.path.join(mock, "la_gpu_mock.c")] + [os.path.join(orc, f) for f in ("orc_hash.c", "orc_lz4.c", "orc_inflate.c")]
     subprocess.check_call(["gcc", "-O1", "-g", "-fPIC", "-std=gnu11", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
                            "-I" + os.path.join(ROOT, "include"), "-shared", "-o", os.path.join(mock, "libla_host_mock_asan.so")] + srcs)

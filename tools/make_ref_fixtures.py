@@ -37,6 +37,57 @@ FIXTURES = [
 ]
 
 
+# ZIP fixtures of the reference's zip reader tests: stored / deflate entries the GPU reader takes, plus
+# two with methods it must refuse per entry like the reference does.  Expected entry contents come from Python's
+# zipfile over the same bytes (names, sizes, CRC32, sha256 of the body) -- the data, not any reference source text.
+ZIP_FIXTURES = ["test_read_format_zip.zip", "test_read_format_zip_7075_utf8_paths.zip", "test_read_format_zip_7z_deflate.zip",
+                "test_read_format_zip_comment_stored_1.zip", "test_read_format_zip_comment_stored_2.zip",
+                "test_read_format_zip_high_compression.zip", "test_read_format_zip_jar.jar",
+                "test_read_format_zip_length_at_end.zip", "test_read_format_zip_mac_metadata.zip",
+                "test_read_format_zip_msdos.zip", "test_read_format_zip_nested.zip", "test_read_format_zip_nofiletype.zip",
+                "test_read_format_zip_padded2.zip", "test_read_format_zip_symlink.zip", "test_read_format_zip_ux.zip",
+                "test_read_format_zip_zip64a.zip", "test_read_format_zip_zip64b.zip",
+                "test_read_format_zip_with_invalid_traditional_eocd.zip",
+                "test_read_format_zip_7z_lzma.zip", "test_read_format_zip_bzip2.zipx"]
+
+
+def make_zip_fixtures():
+    import io, zipfile
+    out = os.path.join(OUT, "zip")
+    os.makedirs(out, exist_ok=True)
+    manifest = []
+    for name in ZIP_FIXTURES:
+        rel = "libarchive/test/%s.uu" % name
+        raw = uudecode(open(os.path.join(REF, rel), "r", errors="replace").read())
+        open(os.path.join(out, name), "wb").write(raw)
+        z = zipfile.ZipFile(io.BytesIO(raw))
+        ents = []
+        for i in z.infolist():
+            e = {"name_latin1": i.orig_filename.encode("utf-8" if i.flag_bits & 0x800 else "cp437", "replace").decode("latin-1"),
+                 "size": i.file_size, "crc": i.CRC, "method": i.compress_type, "encrypted": bool(i.flag_bits & 1),
+                 "is_dir": i.is_dir()}
+            if i.compress_type in (0, 8) and not (i.flag_bits & 1):
+                try:
+                    e["sha256"] = hashlib.sha256(z.read(i)).hexdigest()
+                except zipfile.BadZipFile as err:
+                    if "Bad CRC-32" in str(err):
+                        e["bad_crc"] = True     # deliberately wrong check value (test_read_format_zip.c expects ARCHIVE_FAILED)
+                    else:
+                        # zipfile objects to something else (e.g. names that differ between the two headers): take the
+                        # bytes the directory points at
+                        import struct, zlib
+                        nl, el = struct.unpack_from("<HH", raw, i.header_offset + 26)
+                        o = i.header_offset + 30 + nl + el
+                        body = raw[o:o + i.compress_size]
+                        body = zlib.decompress(body, -15) if i.compress_type == 8 else body
+                        assert zlib.crc32(body) == i.CRC and len(body) == i.file_size
+                        e["sha256"] = hashlib.sha256(body).hexdigest()
+            ents.append(e)
+        manifest.append({"file": name, "source": rel, "stream_sha256": hashlib.sha256(raw).hexdigest(), "entries": ents})
+        print(name, len(raw), len(ents))
+    json.dump(manifest, open(os.path.join(out, "manifest.json"), "w"), indent=1)
+
+
 def uudecode(text):
     out = bytearray()
     started = False
@@ -68,6 +119,7 @@ def main():
                          "decoded_sha256": sha, "pins": note, "stream_sha256": hashlib.sha256(raw).hexdigest()})
         print(name, len(raw))
     json.dump(manifest, open(os.path.join(OUT, "manifest.json"), "w"), indent=1)
+    make_zip_fixtures()
 
 
 if __name__ == "__main__":
