@@ -45,7 +45,14 @@
  *   - no wait for a sequence touched only in its literals          27.8 -> 26.9
  *   - short (4..7 byte) matches in the same load batch            26.9 -> 24.8
  *   - one look at the flag word per iteration                      24.8 -> 23.5
- * and slower, so not kept: wave-cooperative match copies (four matches per pass
+ *   - round 2: 16-byte unaligned accesses for matches of 16 bytes and more, two
+ *     8-byte ones below, no load a lane does not need (an unaligned LDS access
+ *     costs one cycle per active lane whatever its width)         23.2 -> 21.7
+ * and slower, so not kept: neighbouring literal dwords paired into 8-byte stores
+ * (22.3 from 21.7: the extra predicates cost more than the lane-stores saved),
+ * skipping the register slots beyond the block's last sequence in the prepass and
+ * the search (no change: those phases wait for memory, not for issue slots),
+ * wave-cooperative match copies (four matches per pass
  * through ds_bpermute, 35.1), flag look requested one iteration ahead (28.3),
  * speculative source read behind the flag look (27.6), 8-ary search (26.9 from
  * 23.5: more LDS instructions), per-sequence literal copies from global memory
@@ -92,6 +99,8 @@ __device__ unsigned long long *la_diag_stamps;
 __device__ __forceinline__ uint64_t lds_ld8(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
 __device__ __forceinline__ void lds_st8(uint8_t *p, uint64_t v) { __builtin_memcpy(p, &v, 8); }
 __device__ __forceinline__ void lds_st4(uint8_t *p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
+__device__ __forceinline__ uint4 lds_ld16(const uint8_t *p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }
+__device__ __forceinline__ void lds_st16(uint8_t *p, uint4 v) { __builtin_memcpy(p, &v, 16); }
 __device__ __forceinline__ void lds_st2(uint8_t *p, uint16_t v) { __builtin_memcpy(p, &v, 2); }
 
 /* store the low n (< 8) bytes of v */
@@ -491,53 +500,49 @@ __global__ __launch_bounds__(FAST_THREADS, FAST_MIN_WAVES) void lz4_expand_fast_
 						 * ENDS with the match -- overlapping stores instead of a cascade of
 						 * 4/2/1-byte ones.  Loads may run past the source into later window
 						 * bytes or the slack behind the window; stores never pass the match. */
-						{
-							/* first 64 bytes: one batch of loads serves short and long matches alike */
-							uint64_t a[8];
-							/* an LDS instruction costs the same for one lane as for 64: the upper
-							 * half of the batch is only issued when some lane here needs it */
-							a[0] = lds_ld8(fp); a[1] = lds_ld8(fp + 8); a[2] = lds_ld8(fp + 16); a[3] = lds_ld8(fp + 24);
-							a[4] = a[5] = a[6] = a[7] = 0;
-							if (__ballot(mlen > 32) != 0) {
-								a[4] = lds_ld8(fp + 32); a[5] = lds_ld8(fp + 40);
-								if (__ballot(mlen > 48) != 0) {
-									a[6] = lds_ld8(fp + 48); a[7] = lds_ld8(fp + 56);
+						/* An unaligned LDS access costs one cycle per ACTIVE LANE whatever its width
+						 * (tools/ubench_lds.hip), and this phase runs at the speed of the LDS pipe: so
+						 * every lane moves its match with as few, as wide accesses as it takes --
+						 * 16-byte pieces from 16 bytes up (the last one placed so that it ENDS with the
+						 * match: overlapping stores instead of a ragged tail), two 8-byte ones below that,
+						 * one 8-byte load and two 4-byte stores below 8.  All loads of a step are issued
+						 * before anything is stored.  Nothing is read outside the source from 8 bytes up. */
+						if (mlen >= 16) {
+							for (uint32_t i = 0;; i += 32) {	/* one trip up to 47 bytes */
+								const uint32_t left = mlen - i;
+								const uint4 v0 = lds_ld16(fp + i);
+								uint4 v1 = v0, vt = v0;
+								if (left >= 32)
+									v1 = lds_ld16(fp + i + 16);
+								const bool last = left < 48;	/* 16..47 bytes left: this trip ends the match */
+								if (last && (left & 15))
+									vt = lds_ld16(fp + mlen - 16);
+								lds_st16(mp + i, v0);
+								if (left >= 32)
+									lds_st16(mp + i + 16, v1);
+								if (last) {
+									if (left & 15)
+										lds_st16(mp + mlen - 16, vt);
+									break;
 								}
 							}
-							const uint32_t n = mlen < 64 ? mlen : 64;
-							const uint64_t tail = lds_ld8(fp + (n >= 8 ? n - 8 : 0));
+						} else if (mlen >= 8) {
+							const uint64_t a0 = lds_ld8(fp), at = lds_ld8(fp + mlen - 8);
+							lds_st8(mp, a0);
+							if (mlen != 8)
+								lds_st8(mp + mlen - 8, at);
+						} else {
+							const uint64_t a0 = lds_ld8(fp);	/* (may read up to 7 bytes past the source: window bytes or slack) */
 							if (mlen < 4) {
 								/* 1..3 bytes: only the deflate front end makes these (LZ4 matches are
 								 * at least four bytes long) */
-								lds_st_tail(mp, a[0], mlen);
-							} else if (mlen < 8) {
-								/* 4 <= mlen <= 7: two overlapping 4-byte stores */
-								lds_st4(mp, (uint32_t)a[0]);
-								lds_st4(mp + mlen - 4, (uint32_t)(a[0] >> (8 * (mlen - 4))));
+								lds_st_tail(mp, a0, mlen);
 							} else {
-								const uint32_t full = n >> 3;
-#pragma unroll
-								for (int j = 0; j < 8; j++)
-									if ((uint32_t)j < full)
-										lds_st8(mp + 8 * j, a[j]);
-								if (n & 7)
-									lds_st8(mp + n - 8, tail);
+								/* 4 <= mlen <= 7: two overlapping 4-byte stores */
+								lds_st4(mp, (uint32_t)a0);
+								if (mlen != 4)
+									lds_st4(mp + mlen - 4, (uint32_t)(a0 >> (8 * (mlen - 4))));
 							}
-						}
-						for (uint32_t i = 64; i < mlen; i += 64) {
-							uint64_t a[8];
-#pragma unroll
-							for (int j = 0; j < 8; j++)
-								a[j] = lds_ld8(fp + i + 8 * j);
-							const uint32_t n = mlen - i < 64 ? mlen - i : 64;
-							const uint64_t tail = lds_ld8(fp + i + n - 8);	/* i >= 64: never before the source */
-							const uint32_t full = n >> 3;
-#pragma unroll
-							for (int j = 0; j < 8; j++)
-								if ((uint32_t)j < full)
-									lds_st8(mp + i + 8 * j, a[j]);
-							if (n & 7)
-								lds_st8(mp + i + n - 8, tail);
 						}
 					} else if (off >= 8) {
 						/* overlapping, period >= 8: a forward 8-byte copy only reads bytes
