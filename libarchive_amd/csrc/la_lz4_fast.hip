@@ -51,7 +51,10 @@
  * and slower, so not kept: neighbouring literal dwords paired into 8-byte stores
  * (22.3 from 21.7: the extra predicates cost more than the lane-stores saved),
  * skipping the register slots beyond the block's last sequence in the prepass and
- * the search (no change: those phases wait for memory, not for issue slots),
+ * the search (no change: those phases wait for memory, not for issue slots), a match
+ * phase in two passes (every slot gets one to three looks, the stragglers of all slots
+ * are taken in a second pass: 23.3 / 23.5 / 23.8 from 21.8 -- the lanes a slot waits for
+ * are not a few stragglers, the whole in-flight set advances one dependency level per look),
  * wave-cooperative match copies (four matches per pass
  * through ds_bpermute, 35.1), flag look requested one iteration ahead (28.3),
  * speculative source read behind the flag look (27.6), 8-ary search (26.9 from

@@ -114,8 +114,18 @@ static int gzip_bidder_bid(struct archive_read_filter_bidder *self, struct archi
 	/* optional fields: like the reference's parser (gzip.c:183-194), extend the peek one
 	 * byte at a time until the header parses or upstream cannot supply another byte */
 	for (;;) {
-		if (la_gz_header_parse(p, (size_t)avail, NULL))
+		la_gz_header h;
+		if (la_gz_header_parse(p, (size_t)avail, &h)) {
+			/* Deployment switch: with LA_GZIP_BID_ONLY_INDEXED=1 this bidder takes only
+			 * streams whose first member carries the BGZF "BC" size subfield -- the many-member shape the
+			 * device path is built for -- and bids 0 on anything else, so that the reference's own gzip
+			 * bidder, registered beside it, wins ordinary single-member .gz files (one serial deflate
+			 * chain decodes faster on a host core than on one GPU wave). */
+			const char *only = getenv("LA_GZIP_BID_ONLY_INDEXED");
+			if (only && only[0] == '1' && h.bgzf_size == 0)
+				return 0;
 			return 27;
+		}
 		p = __archive_read_filter_ahead(filter, (size_t)avail + 1, &avail);
 		if (p == NULL)
 			return 0;

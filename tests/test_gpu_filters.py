@@ -452,3 +452,18 @@ def test_lz4_window_bounded_by_decoded_bytes(gpu_ctx, monkeypatch):
         assert la_api.as_reference_tuple(r) == want, variant
         if variant == 0:
             assert len(r.block_sizes) >= 8  # many bounded windows, not one huge slab
+
+
+def test_gzip_bid_only_indexed_switch(gpu_ctx, monkeypatch):
+    """LA_GZIP_BID_ONLY_INDEXED=1: the bidder declines streams without the BGZF size subfield (a deployment
+    leaves those to the reference's bidder); with no other gzip bidder registered here the bytes then come
+    through unfiltered.  BGZF-style streams are taken as before."""
+    plain = b"some text " * 1000
+    ordinary, indexed = S.gz_member(plain), _bgzf_member(plain)
+    r = la_api.cat(ordinary)
+    assert r.filters[0] == (1, "gzip") and r.data == plain
+    monkeypatch.setenv("LA_GZIP_BID_ONLY_INDEXED", "1")
+    r = la_api.cat(ordinary)
+    assert r.filters[0][1] != "gzip" and r.data == ordinary
+    r = la_api.cat(indexed)
+    assert r.filters[0] == (1, "gzip") and r.data == plain

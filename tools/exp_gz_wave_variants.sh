@@ -1,8 +1,8 @@
 #!/bin/bash
 # wave-per-member inflate kernel of several builds (libla_gpu_<name>.so), forced with option 2 (diagnostic)
-cp libarchive_amd/csrc/libla_gpu.so /tmp/libla_gpu_keep.so
+# builds are selected through LA_GPU_LIB (libarchive_amd/_native.py): the shipped libla_gpu.so is never overwritten
 for v in "$@"; do
-  cp libarchive_amd/csrc/libla_gpu_$v.so libarchive_amd/csrc/libla_gpu.so
+  export LA_GPU_LIB=$PWD/libarchive_amd/csrc/libla_gpu_$v.so
   for mib in 16 256 1024; do
     gib=$(python -c "print($mib/1024)")
     echo -n "$v decoded $mib MiB ($((mib*16)) members): "
@@ -10,4 +10,3 @@ for v in "$@"; do
       | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['bit_exact'], d['ms_per_step'], d['phases_ms'])"
   done
 done
-cp /tmp/libla_gpu_keep.so libarchive_amd/csrc/libla_gpu.so
