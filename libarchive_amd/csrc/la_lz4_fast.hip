@@ -55,6 +55,8 @@
  * phase in two passes (every slot gets one to three looks, the stragglers of all slots
  * are taken in a second pass: 23.3 / 23.5 / 23.8 from 21.8 -- the lanes a slot waits for
  * are not a few stragglers, the whole in-flight set advances one dependency level per look),
+ * pulling the table and payload of the block 512 / 1024 / 2048 places ahead towards L2 at the
+ * start of the match phase (22.4 / 22.5 / 22.8 from 21.8: the prepass is not waiting for HBM),
  * wave-cooperative match copies (four matches per pass
  * through ds_bpermute, 35.1), flag look requested one iteration ahead (28.3),
  * speculative source read behind the flag look (27.6), 8-ary search (26.9 from
