@@ -61,6 +61,13 @@ struct gzip_private {
 	/* header metadata (gzip.c:280-296) */
 	uint32_t mtime;
 	char *name;
+	/* the window whose device work is queued but not yet looked at (decode-ahead: it was gathered,
+	 * uploaded, indexed and launched BEFORE the previous read() returned, so the device works on it
+	 * while the caller consumes the slab it was given) */
+	la_gz_index idx;
+	int inflight;
+	size_t o_res;
+	int upstream_failed;	/* upstream reported an error while the next window was gathered ahead */
 	int pending_fatal;
 	int pending_has_msg;
 	char pending_msg[128];
@@ -228,7 +235,7 @@ static void gz_set_fatal(struct gzip_private *st, const char *msg)
  * delivered (everything, unless an error follows).
  */
 static int gzip_run_batch(struct archive_read_filter *self, struct gzip_private *st,
-    const la_gz_index *x, size_t *used)
+    const la_gz_index *x, size_t *used, int phase /* 0: queue the device work; 1: results, stream-order walk, slab */)
 {
 	const uint32_t n = x->n;
 	size_t o = 0;
@@ -236,14 +243,15 @@ static int gzip_run_batch(struct archive_read_filter *self, struct gzip_private 
 	const size_t o_res = o; o += ALIGN256((size_t)n * sizeof(la_gz_result));
 	const size_t o_sum = o; o += 256;
 	size_t src_len = (size_t)x->consumed;
-	if (gz_grow_dev(st, &st->d_src, &st->d_src_cap, src_len + 64) < 0 ||
-	    gz_grow_dev(st, &st->d_dst, &st->d_dst_cap, (size_t)x->max_out + 64) < 0 ||
-	    gz_grow_dev(st, &st->d_tabs, &st->d_tabs_cap, o) < 0)
+	if (phase == 0 &&
+	    (gz_grow_dev(st, &st->d_src, &st->d_src_cap, src_len + 64) < 0 ||
+	     gz_grow_dev(st, &st->d_dst, &st->d_dst_cap, (size_t)x->max_out + 64) < 0 ||
+	     gz_grow_dev(st, &st->d_tabs, &st->d_tabs_cap, o) < 0))
 		return gz_gpu_fail(self, st, "device allocation");
 	uint8_t *T = st->d_tabs;
 	const double b0 = st->trace ? gz_now() : 0;
-	/* (the compressed bytes are already on their way: gzip_filter_read) */
-	if (la_gpu_memcpy_h2d(st->gpu, T + o_mem, x->members, (size_t)n * sizeof(la_gz_member)) != LA_OK)
+	/* (the compressed bytes are already on their way: gz_prepare) */
+	if (phase == 0 && la_gpu_memcpy_h2d(st->gpu, T + o_mem, x->members, (size_t)n * sizeof(la_gz_member)) != LA_OK)
 		return gz_gpu_fail(self, st, "host to device copy");
 	la_gz_batch bt;
 	memset(&bt, 0, sizeof(bt));
@@ -252,8 +260,11 @@ static int gzip_run_batch(struct archive_read_filter *self, struct gzip_private 
 	bt.d_dst = st->d_dst; bt.dst_cap = x->max_out;
 	bt.d_results = (la_gz_result *)(T + o_res);
 	bt.d_summary = (la_batch_summary *)(T + o_sum);
-	if (la_gpu_gzip_decode(st->gpu, &bt) != LA_OK)
-		return gz_gpu_fail(self, st, "la_gpu_gzip_decode");
+	if (phase == 0) {
+		if (la_gpu_gzip_decode(st->gpu, &bt) != LA_OK)
+			return gz_gpu_fail(self, st, "la_gpu_gzip_decode");
+		return 0;
+	}
 	if (st->h_res_cap < n) {
 		free(st->h_res);
 		st->h_res = malloc((size_t)n * sizeof(la_gz_result));
@@ -454,6 +465,88 @@ static int gzip_run_batch(struct archive_read_filter *self, struct gzip_private 
 	return 0;
 }
 
+/*
+ * Gather one window, start its upload, find the member boundaries and queue the decode: nothing is
+ * waited for.  Returns 1 when a window is in flight (st->idx, st->inflight), 0 when the state changed
+ * instead (end of stream, pending error, wider window, looser boundary search: the caller looks again),
+ * ARCHIVE_FATAL on error.
+ */
+static int gz_prepare(struct archive_read_filter *self, struct gzip_private *st)
+{
+	const double t0 = st->trace ? gz_now() : 0;
+	while (!st->upstream_eof && st->stage_len < st->batch_bytes) {
+		ssize_t avail;
+		const void *up = __archive_read_filter_ahead(self->upstream, 1, &avail);
+		if (up == NULL) {
+			if (avail < 0)
+				return ARCHIVE_FATAL;
+			st->upstream_eof = 1;
+			break;
+		}
+		size_t n = (size_t)avail;
+		if (n > st->batch_bytes - st->stage_len)
+			n = st->batch_bytes - st->stage_len;
+		/* a stream that has already filled 8 MiB gets the whole window at once instead of
+		 * five more rounds of pin-a-bigger-buffer-and-copy */
+		size_t want = st->stage_len + n;
+		if (want > ((size_t)8 << 20) && want < st->batch_bytes)
+			want = st->batch_bytes;
+		if (gz_grow_pinned(st, &st->stage, &st->stage_cap, want, st->stage_len) < 0)
+			return gz_gpu_fail(self, st, "pinned staging allocation");
+		memcpy(st->stage + st->stage_len, up, n);
+		st->stage_len += n;
+		__archive_read_filter_consume(self->upstream, (int64_t)n);
+	}
+	const double t1 = st->trace ? gz_now() : 0;
+	/* the window goes to the device while the host looks for the member boundaries in it
+	 * (stream-ordered copy from the pinned window; nothing writes to [0, stage_len)
+	 * before the batch has been waited for) */
+	if (st->stage_len &&
+	    (gz_grow_dev(st, &st->d_src, &st->d_src_cap, st->stage_len + 64) < 0 ||
+	     la_gpu_memcpy_h2d(st->gpu, st->d_src, st->stage, st->stage_len) != LA_OK))
+		return gz_gpu_fail(self, st, "host to device copy");
+	if (la_gz_index_build3(st->stage, st->stage_len, st->upstream_eof, st->hint_skip, st->hint_cap,
+	    st->loose ? 0 : LA_GZ_INDEX_STRICT, &st->idx) != 0) {
+		archive_set_error(&self->archive->archive, ENOMEM, "Can't allocate data for gzip decompression");
+		return ARCHIVE_FATAL;
+	}
+	if (st->idx.n == 0) {
+		int kind = st->idx.end_kind;
+		la_gz_index_free(&st->idx);
+		if (la_gpu_sync(st->gpu) != LA_OK)	/* the upload above: the window may move now */
+			return gz_gpu_fail(self, st, "host to device copy");
+		if (kind == LA_END_NEED_MORE) {
+			if (st->upstream_eof) { st->eof = 1; return 0; }
+			if (!st->loose) {
+				/* no trusted boundary in the whole window: before widening it, look
+				 * with every 1f 8b 08 as a candidate (and keep doing so) */
+				st->loose = 1;
+				return 0;
+			}
+			st->batch_bytes *= 2;	/* one member larger than the window */
+			return 0;
+		}
+		if (kind == LA_END_TRUNCATED)
+			gz_set_fatal(st, "truncated gzip input");
+		else if (kind == LA_END_GZ_TOO_LARGE)
+			gz_set_fatal(st, la_end_message(LA_END_GZ_TOO_LARGE, 1));
+		else
+			st->eof = 1;
+		return 0;
+	}
+	size_t used = 0;
+	int rc = gzip_run_batch(self, st, &st->idx, &used, 0);
+	if (rc < 0) {
+		la_gz_index_free(&st->idx);
+		return rc;
+	}
+	st->inflight = 1;
+	if (st->trace)
+		fprintf(stderr, "la_gzip: window %zu bytes, %u members queued: gather %.1f ms, index + launch %.1f ms\n",
+		    st->stage_len, st->idx.n, t1 - t0, gz_now() - t1);
+	return 1;
+}
+
 static ssize_t gzip_filter_read(struct archive_read_filter *self, const void **p)
 {
 	struct gzip_private *st = (struct gzip_private *)self->data;
@@ -479,76 +572,24 @@ static ssize_t gzip_filter_read(struct archive_read_filter *self, const void **p
 			}
 			return 0;
 		}
-		const double t0 = st->trace ? gz_now() : 0;
-		while (!st->upstream_eof && st->stage_len < st->batch_bytes) {
-			ssize_t avail;
-			const void *up = __archive_read_filter_ahead(self->upstream, 1, &avail);
-			if (up == NULL) {
-				if (avail < 0)
-					return ARCHIVE_FATAL;
-				st->upstream_eof = 1;
-				break;
-			}
-			size_t n = (size_t)avail;
-			if (n > st->batch_bytes - st->stage_len)
-				n = st->batch_bytes - st->stage_len;
-			/* a stream that has already filled 8 MiB gets the whole window at once instead of
-			 * five more rounds of pin-a-bigger-buffer-and-copy */
-			size_t want = st->stage_len + n;
-			if (want > ((size_t)8 << 20) && want < st->batch_bytes)
-				want = st->batch_bytes;
-			if (gz_grow_pinned(st, &st->stage, &st->stage_cap, want, st->stage_len) < 0)
-				return gz_gpu_fail(self, st, "pinned staging allocation");
-			memcpy(st->stage + st->stage_len, up, n);
-			st->stage_len += n;
-			__archive_read_filter_consume(self->upstream, (int64_t)n);
-		}
-		const double t1 = st->trace ? gz_now() : 0;
-		/* the window goes to the device while the host looks for the member boundaries in it
-		 * (stream-ordered copy from the pinned window; nothing below writes to [0, stage_len)
-		 * before the batch has been waited for) */
-		if (st->stage_len &&
-		    (gz_grow_dev(st, &st->d_src, &st->d_src_cap, st->stage_len + 64) < 0 ||
-		     la_gpu_memcpy_h2d(st->gpu, st->d_src, st->stage, st->stage_len) != LA_OK))
-			return gz_gpu_fail(self, st, "host to device copy");
-		la_gz_index idx;
-		if (la_gz_index_build3(st->stage, st->stage_len, st->upstream_eof, st->hint_skip, st->hint_cap,
-		    st->loose ? 0 : LA_GZ_INDEX_STRICT, &idx) != 0) {
-			archive_set_error(&self->archive->archive, ENOMEM, "Can't allocate data for gzip decompression");
-			return ARCHIVE_FATAL;
-		}
-		if (idx.n == 0) {
-			int kind = idx.end_kind;
-			la_gz_index_free(&idx);
-			if (la_gpu_sync(st->gpu) != LA_OK)	/* the upload above: the window may move now */
-				return gz_gpu_fail(self, st, "host to device copy");
-			if (kind == LA_END_NEED_MORE) {
-				if (st->upstream_eof) { st->eof = 1; continue; }
-				if (!st->loose) {
-					/* no trusted boundary in the whole window: before widening it, look
-					 * with every 1f 8b 08 as a candidate (and keep doing so) */
-					st->loose = 1;
-					continue;
-				}
-				st->batch_bytes *= 2;	/* one member larger than the window */
+		if (!st->inflight) {
+			if (st->upstream_failed)
+				return ARCHIVE_FATAL;	/* upstream set the error when the window was gathered ahead */
+			int pr = gz_prepare(self, st);
+			if (pr < 0)
+				return pr;
+			if (pr == 0)
 				continue;
-			}
-			if (kind == LA_END_TRUNCATED)
-				gz_set_fatal(st, "truncated gzip input");
-			else if (kind == LA_END_GZ_TOO_LARGE)
-				gz_set_fatal(st, la_end_message(LA_END_GZ_TOO_LARGE, 1));
-			else
-				st->eof = 1;
-			continue;
 		}
+		/* the window in flight: results, stream-order walk, slab */
 		size_t used = 0;
 		const double t2 = st->trace ? gz_now() : 0;
-		int rc = gzip_run_batch(self, st, &idx, &used);
+		int rc = gzip_run_batch(self, st, &st->idx, &used, 1);
+		st->inflight = 0;
 		int made_progress = used > 0;
 		if (st->trace)
-			fprintf(stderr, "la_gzip: window %zu bytes, %u members: gather %.1f ms, index %.1f ms, batch %.1f ms, used %zu, out %zu\n",
-			    st->stage_len, idx.n, t1 - t0, t2 - t1, gz_now() - t2, used, st->last_ret);
-		la_gz_index_free(&idx);
+			fprintf(stderr, "la_gzip:   finished in %.1f ms, used %zu of %zu, out %zu\n", gz_now() - t2, used, st->stage_len, st->last_ret);
+		la_gz_index_free(&st->idx);
 		if (rc < 0)
 			return rc;
 		if (used < st->stage_len)
@@ -560,6 +601,15 @@ static ssize_t gzip_filter_read(struct archive_read_filter *self, const void **p
 			st->batch_bytes *= 2;
 		}
 		if (st->last_ret) {
+			/* Decode ahead: gather, upload, index and launch the NEXT window before handing this
+			 * slab out, so that the device works while the caller consumes it (the slab is not
+			 * touched until the next read()).  An outcome other than "in flight" is simply met
+			 * again by the next read(). */
+			if (!st->pending_fatal && !st->eof) {
+				int pr = gz_prepare(self, st);
+				if (pr < 0)
+					st->upstream_failed = 1;	/* reported by the next read(), after these bytes */
+			}
 			*p = st->slab;
 			return (ssize_t)st->last_ret;
 		}
@@ -573,6 +623,8 @@ static int gzip_filter_close(struct archive_read_filter *self)
 		return ARCHIVE_OK;
 	if (st->gpu) {
 		la_gpu_sync(st->gpu);
+		if (st->inflight)
+			la_gz_index_free(&st->idx);
 		if (st->stage) la_gpu_free_host(st->gpu, st->stage);
 		if (st->slab) la_gpu_free_host(st->gpu, st->slab);
 		if (st->d_src) la_gpu_free(st->gpu, st->d_src);
