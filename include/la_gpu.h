@@ -248,6 +248,36 @@ typedef struct la_gz_batch {
 
 int la_gpu_gzip_decode(la_gpu_ctx *ctx, const la_gz_batch *batch);
 
+/* =====================================================================
+ * LZ4 compression -- the data plane of the lz4 WRITE filter: replaces, for a whole
+ * stream per call, LZ4_compress_default per independent block, the stored-block fallback, the block
+ * checksum, the frame descriptor with its check byte, the EndMark and the content checksum of
+ * libarchive/archive_write_add_filter_lz4.c:394-447, :484-532.  d_src[0, src_bytes) is cut into blocks
+ * of block_size bytes (at most 64 KiB), blocks_per_frame of them form one frame; d_out receives the
+ * concatenated frames, *d_out_bytes their total size (if it exceeds out_cap nothing past out_cap was
+ * written: call again with a larger buffer; src_bytes + src_bytes/255 + 27 bytes per block always fit).
+ * The bytes are not liblz4's (an LZ4 stream is not unique); every conforming decoder returns the input.
+ * ===================================================================== */
+#define LA_LZ4C_BLOCK_SUM   1u	/* FLG bit 4: XXH32 of every block's payload as written */
+#define LA_LZ4C_CONTENT_SUM 2u	/* FLG bit 2: XXH32 of every frame's input bytes after its EndMark */
+
+typedef struct la_lz4c_batch {
+	const uint8_t *d_src;
+	uint64_t       src_bytes;
+	uint32_t       block_size;		/* 1 .. 65536 */
+	uint32_t       blocks_per_frame;	/* >= 1 */
+	uint32_t       flags;			/* LA_LZ4C_* */
+	uint32_t       reserved;
+	uint8_t       *d_out;
+	uint64_t       out_cap;
+	uint64_t      *d_out_bytes;		/* one u64 on the device */
+} la_lz4c_batch;
+
+uint64_t la_gpu_lz4_compress_workspace_bytes(uint64_t src_bytes, uint32_t block_size, uint32_t blocks_per_frame);
+/* upper bound of the stream la_gpu_lz4_compress writes for this shape */
+uint64_t la_gpu_lz4_compress_bound(uint64_t src_bytes, uint32_t block_size, uint32_t blocks_per_frame);
+int      la_gpu_lz4_compress(la_gpu_ctx *ctx, const la_lz4c_batch *batch);
+
 #ifdef __cplusplus
 }
 #endif

@@ -544,4 +544,36 @@ int la_gpu_gzip_decode(la_gpu_ctx *c, const la_gz_batch *bt)
 	return LA_OK;
 }
 
+/* ------------------------------------------------------------------ lz4 compression */
+
+uint64_t la_gpu_lz4_compress_bound(uint64_t src_bytes, uint32_t block_size, uint32_t bpf)
+{
+	if (block_size == 0 || bpf == 0)
+		return 0;
+	const uint64_t nb = (src_bytes + block_size - 1) / block_size, nf = (nb + bpf - 1) / bpf;
+	return src_bytes + nb * (block_size / 255u + 16u + 8u) + nf * 15u + 64u;
+}
+
+int la_gpu_lz4_compress(la_gpu_ctx *c, const la_lz4c_batch *bt)
+{
+	if (!c || !bt || !bt->d_out_bytes || (bt->src_bytes && (!bt->d_src || !bt->d_out)))
+		return LA_ERR_ARG;
+	if (bt->block_size == 0 || bt->block_size > 65536u || bt->blocks_per_frame == 0 ||
+	    (uint64_t)bt->block_size * bt->blocks_per_frame > 0x7FFFFFFFull ||
+	    (bt->src_bytes + bt->block_size - 1) / bt->block_size > 0xFFFFFFFEull)
+		return LA_ERR_ARG;
+	const uint64_t need = la_gpu_lz4_compress_workspace_bytes(bt->src_bytes, bt->block_size, bt->blocks_per_frame);
+	if (need > c->ws_bytes) {
+		int rc = la_gpu_reserve(c, need);
+		if (rc != LA_OK) return rc;
+	}
+	prof_begin(c);
+	int h = prof_open(c, "lz4_compress", c->stream);
+	la_launch_lz4_compress(c->stream, bt->d_src, bt->src_bytes, bt->block_size, bt->blocks_per_frame, bt->flags,
+	    bt->d_out, bt->out_cap, bt->d_out_bytes, (uint8_t *)c->ws);
+	prof_close(c, h, c->stream);
+	HIPCHK(c, hipGetLastError());
+	return LA_OK;
+}
+
 } /* extern "C" */

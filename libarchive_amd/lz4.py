@@ -131,3 +131,25 @@ def decode_image(ctx, image, device="cuda:0", options=0):
     delivered, rc, msg = plan.resolve()
     out = plan.d_dst[:delivered].cpu().numpy()
     return out, rc, msg, plan
+
+
+def compress_to_frames(ctx, d_plain, block_size=65536, blocks_per_frame=16, flags=None):
+    """Device LZ4 compression (la_gpu_lz4_compress): d_plain is a 1-D uint8 CUDA tensor; returns a uint8
+    CUDA tensor holding the concatenated frames (harness for the tests and for stream synthesis)."""
+    torch = _torch()
+    if flags is None:
+        flags = N.LA_LZ4C_BLOCK_SUM | N.LA_LZ4C_CONTENT_SUM
+    n = int(d_plain.numel())
+    cap = int(N.gpu_lib().la_gpu_lz4_compress_bound(n, block_size, blocks_per_frame))
+    d_out = torch.empty(max(cap, 16), dtype=torch.uint8, device=d_plain.device)
+    d_len = torch.zeros(1, dtype=torch.int64, device=d_plain.device)
+    b = N._Lz4cBatchC()
+    b.d_src = d_plain.data_ptr() if n else None
+    b.src_bytes = n
+    b.block_size, b.blocks_per_frame, b.flags = block_size, blocks_per_frame, flags
+    b.d_out, b.out_cap, b.d_out_bytes = d_out.data_ptr(), cap, d_len.data_ptr()
+    ctx.lz4_compress(b)
+    ctx.sync()
+    total = int(d_len.cpu()[0])
+    assert total <= cap, (total, cap)
+    return d_out[:total]
