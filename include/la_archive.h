@@ -74,6 +74,18 @@ int  archive_read_data_into_fd(struct archive *, int fd);			/* archive_read_data
 int  archive_read_close(struct archive *);
 int  archive_read_free(struct archive *);
 
+/* ---- write side: the slice the lz4 write filter needs (host/la_write_lz4.c; archive.h:785-940) ---- */
+struct archive *archive_write_new(void);
+int  archive_write_add_filter_lz4(struct archive *);				/* archive.h:819; archive_write_add_filter_lz4.c:94 */
+int  archive_write_set_format_raw(struct archive *);				/* one entry, data passed through */
+int  archive_write_set_filter_option(struct archive *, const char *m, const char *o, const char *v);	/* "lz4", "block-checksum", "1" ... */
+int  archive_write_open_memory(struct archive *, void *buffer, size_t buffSize, size_t *used);
+int  archive_write_open_fd(struct archive *, int fd);
+int  archive_write_header(struct archive *, struct archive_entry *);
+ssize_t archive_write_data(struct archive *, const void *, size_t);
+int  archive_write_close(struct archive *);
+int  archive_write_free(struct archive *);
+
 const char *archive_error_string(struct archive *);
 int         archive_errno(struct archive *);
 void        archive_set_error(struct archive *, int error_number, const char *fmt, ...)
