@@ -193,3 +193,49 @@ int la_gpu_crc32_many(la_gpu_ctx *c, const uint8_t *d_base, const la_hash_job *d
 		d_out[i] = orc_crc32(d_jobs[i].seed, d_base + d_jobs[i].off, d_jobs[i].len);
 	return LA_OK;
 }
+
+/* lz4 compression stand-in: every block becomes ONE literal-only sequence (a valid LZ4 block that never
+ * shrinks, so the frames carry stored blocks) -- enough for the host-side write filter logic */
+uint64_t la_gpu_lz4_compress_workspace_bytes(uint64_t s, uint32_t b, uint32_t f) { (void)s; (void)b; (void)f; return 0; }
+uint64_t la_gpu_lz4_compress_bound(uint64_t src_bytes, uint32_t block_size, uint32_t bpf)
+{
+	if (block_size == 0 || bpf == 0) return 0;
+	const uint64_t nb = (src_bytes + block_size - 1) / block_size, nf = (nb + bpf - 1) / bpf;
+	return src_bytes + nb * (block_size / 255u + 16u + 8u) + nf * 15u + 64u;
+}
+static void mock_le32(uint8_t *p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); }
+int la_gpu_lz4_compress(la_gpu_ctx *c, const la_lz4c_batch *bt)
+{
+	(void)c;
+	if (!bt || bt->block_size == 0 || bt->block_size > 65536u || bt->blocks_per_frame == 0)
+		return LA_ERR_ARG;
+	uint64_t o = 0;
+	const uint64_t nb = (bt->src_bytes + bt->block_size - 1) / bt->block_size;
+	for (uint64_t i = 0; i < nb; i++) {
+		const uint64_t so = i * bt->block_size;
+		const uint32_t n = (uint32_t)(bt->src_bytes - so < bt->block_size ? bt->src_bytes - so : bt->block_size);
+		if (i % bt->blocks_per_frame == 0) {
+			const uint8_t flg = (uint8_t)(0x60 | ((bt->flags & LA_LZ4C_BLOCK_SUM) ? 0x10 : 0) | ((bt->flags & LA_LZ4C_CONTENT_SUM) ? 0x04 : 0));
+			uint8_t d[2] = { flg, 0x40 };
+			if (o + 7 > bt->out_cap) return LA_ERR_ARG;
+			mock_le32(bt->d_out + o, 0x184D2204u);
+			bt->d_out[o + 4] = d[0]; bt->d_out[o + 5] = d[1];
+			bt->d_out[o + 6] = (uint8_t)(orc_xxh32(d, 2, 0) >> 8);
+			o += 7;
+		}
+		if (o + 4 + n + 12 > bt->out_cap) return LA_ERR_ARG;
+		mock_le32(bt->d_out + o, n | 0x80000000u);	/* stored */
+		memcpy(bt->d_out + o + 4, bt->d_src + so, n);
+		o += 4 + n;
+		if (bt->flags & LA_LZ4C_BLOCK_SUM) { mock_le32(bt->d_out + o, orc_xxh32(bt->d_src + so, n, 0)); o += 4; }
+		if (i % bt->blocks_per_frame == bt->blocks_per_frame - 1 || i + 1 == nb) {
+			mock_le32(bt->d_out + o, 0); o += 4;
+			if (bt->flags & LA_LZ4C_CONTENT_SUM) {
+				const uint64_t fo = (i / bt->blocks_per_frame) * (uint64_t)bt->blocks_per_frame * bt->block_size;
+				mock_le32(bt->d_out + o, orc_xxh32(bt->d_src + fo, (size_t)(so + n - fo), 0)); o += 4;
+			}
+		}
+	}
+	*bt->d_out_bytes = o;
+	return LA_OK;
+}

@@ -17,7 +17,10 @@ ARCHIVE_OK, ARCHIVE_FAILED, ARCHIVE_FATAL = 0, -25, -30
 
 
 def _lib():
-    lib = la.host_lib()
+    return _lib_setup(la.host_lib())
+
+
+def _lib_setup(lib):
     lib.archive_write_new.restype = C.c_void_p
     for f in ("archive_write_add_filter_lz4", "archive_write_set_format_raw", "archive_write_close", "archive_write_free"):
         getattr(lib, f).argtypes = [C.c_void_p]

@@ -68,6 +68,24 @@ from test_gpu_zip import (  # noqa: E402,F401
 )
 
 
+def test_write_filter_host_logic_on_the_mock(gpu_ctx, monkeypatch):
+    """The lz4 write filter's host side (windows, options, frame hand-off, empty stream, client errors) against the
+    mock device (which stores every block): what it writes reads back through the read path."""
+    import ctypes as C
+    import random
+    import test_gpu_lz4_write as W
+    mock = C.CDLL(os.path.join(MOCK_DIR, "libla_host_mock.so"))
+    monkeypatch.setattr(W, "_lib", lambda: W._lib_setup(mock))
+    monkeypatch.setenv("LA_GPU_WRITE_WINDOW_MIB", "1")
+    rnd = random.Random(31)
+    for size in (0, 1, 65536, (1 << 20) + 7, 3 * (1 << 20) + 999):
+        data = rnd.randbytes(size)
+        for opts in ((), (("block-checksum", "1"),), (("stream-checksum", None), ("block-size", "5"))):
+            rc, img = W.write_lz4(data, opts, rnd.choice([None, 4097]))
+            assert rc == 0 and la_api.cat(img).data == data
+    W.test_write_filter_options_and_errors(None)
+
+
 def test_mock_library_is_not_the_product(gpu_ctx):
     """Guard: the product library must not resolve to the mock, and vice versa."""
     import libarchive_amd as la

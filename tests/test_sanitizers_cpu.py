@@ -97,6 +97,21 @@ for img in (tar, _gz_members(tar), _lz4_frames(tar)):
         la_api.list_entries(m, read_size=rnd.choice([None, 512, 4096]), skip_every=rnd.choice([0, 2]))
         la_api.cat(m, read_size=rnd.choice([None, 1000]))
         n += 2
+# lz4 write filter: windows, pieces, options, a client buffer that is too small
+import test_gpu_lz4_write as W
+W._lib = lambda _l=C.CDLL(os.path.join(ROOT, "tests", "mock_gpu", "libla_host_mock_asan.so")): W._lib_setup(_l)
+os.environ["LA_GPU_WRITE_WINDOW_MIB"] = "1"
+for size in (0, 1, 65535, 65536, 1 << 20, (1 << 20) + 1, 3 * (1 << 20) + 12345):
+    data = bytes(rnd.getrandbits(8) for _ in range(min(size, 4096))) * (size // 4096 + 1)
+    data = data[:size]
+    for opts in ((), (("block-checksum", "1"),), (("stream-checksum", None),)):
+        rc, img = W.write_lz4(data, opts, rnd.choice([None, 1000, 70000]))
+        assert rc == 0
+        r = la_api.cat(img)
+        assert r.data == data, (size, opts)
+        n += 1
+    rc, err = W.write_lz4(data, (), None, cap=max(1, size // 2))
+    n += 1
 # ZIP reader: mutated archives (directory records, local headers, bodies, end record) must fail cleanly
 from test_gpu_zip import _make_zip
 import zipfile
@@ -149,7 +164,7 @@ def test_filters_read_core_and_tar_walker_under_asan_ubsan(tmp_path):
     mock = os.path.join(ROOT, "tests", "mock_gpu")
     orc = os.path.join(ROOT, "oracle")
     srcs = [os.path.join(host, f) for f in ("la_lz4_index.c", "la_gzip_index.c", "la_read_core.c", "la_format_tar.c",
-                                            "la_format_zip.c", "la_hash_dropin.c", "la_filter_lz4.c", "la_filter_gzip.c")]
+                                            "la_format_zip.c", "la_hash_dropin.c", "la_write_lz4.c", "la_filter_lz4.c", "la_filter_gzip.c")]
     srcs += [os.path.join(mock, "la_gpu_mock.c")] + [os.path.join(orc, f) for f in ("orc_hash.c", "orc_lz4.c", "orc_inflate.c")]
     subprocess.check_call(["gcc", "-O1", "-g", "-fPIC", "-std=gnu11", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
                            "-I" + os.path.join(ROOT, "include"), "-shared", "-o", os.path.join(mock, "libla_host_mock_asan.so")] + srcs)
