@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--unique-mib", type=int, default=1024, help="unique decoded MiB generated on the host, tiled on device")
     ap.add_argument("--cpu-sample-mib", type=int, default=1024, help="decoded MiB the CPU baseline decodes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--api-mib", type=int, default=8192, help="decoded MiB of the A-level (la_cat) measurement, 0 = skip")
+    ap.add_argument("--api-mib", type=int, default=16384, help="decoded MiB of the A-level (la_cat) measurement, 0 = skip")
     ap.add_argument("--general-only", action="store_true", help="force the general expand kernel")
     ap.add_argument("--extra-options", type=int, default=0, help="diagnostic: extra LA_LZ4_OPT_* bits")
     ap.add_argument("--gather", action="store_true", default=os.environ.get("LA_BENCH_GATHER", "") == "1",
@@ -393,12 +393,24 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
+    # LA_BENCH_BACKEND=gloo is the REHEARSAL of the N > 1 path on a box with fewer GPUs than ranks: the ranks
+    # share the devices there are and the collectives run on CPU tensors.  The measured configuration is nccl
+    # (= RCCL over xGMI), one GPU per rank; a rehearsal line says so in `config`.
+    backend = os.environ.get("LA_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and world > ndev:
+        sys.exit("bench.py: %d ranks but %d GPU(s) visible" % (world, ndev))
+    local = local % ndev
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    coll_device = device if backend == "nccl" else torch.device("cpu")
 
     ctx = la.GpuContext(local)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -440,7 +452,7 @@ def main():
 
     # the only exchange: per-rank summaries (no decoded bytes move; outputs stay sharded)
     from libarchive_amd.shard import exchange_summaries
-    dt_max, U_all, C_all, ok_all = exchange_summaries(dist, device, dt, U_bytes, C_bytes, ok)
+    dt_max, U_all, C_all, ok_all = exchange_summaries(dist, coll_device, dt, U_bytes, C_bytes, ok)
 
     # explicit "single stream split" mode: the decoded ranges gathered to rank 0 over RCCL, timed on its own
     gather = None
@@ -448,7 +460,7 @@ def main():
         from libarchive_amd.shard import gather_ranges_into
         barrier()
         t0 = time.perf_counter()
-        buf, slot, sizes = gather_ranges_into(dist, device, plan.d_dst[:U_bytes], root=0)
+        buf, slot, sizes = gather_ranges_into(dist, coll_device, plan.d_dst[:U_bytes].to(coll_device), root=0)
         barrier()
         dt_g = time.perf_counter() - t0
         if rank == 0:
@@ -511,6 +523,7 @@ def main():
                 "parallelism": "ONE stream of %d x %.0f GiB cut on frame boundaries into %d ranges balanced by C+U, one range per GPU, outputs stay sharded"
                                % (world, args.gib, world),
                 "rank0_frame_range": list(info["frame_range"]),
+                "collectives": "RCCL (nccl backend)" if backend == "nccl" else "REHEARSAL: %s on CPU tensors, %d rank(s) sharing %d GPU(s) -- not a scaling measurement" % (backend, world, ndev),
                 "expand_kernel": "general" if args.general_only else "auto",
                 "host_index_ms_per_gib_compressed": round(info["index_s_unique"] * 1e3 / (info["unique_compressed"] / (1 << 30)), 2),
             },
