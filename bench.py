@@ -64,12 +64,11 @@ def parse():
 
 
 def kernel_source_id():
-    """Identifies the build of the dominant kernel a PMC traffic figure belongs to."""
+    """Identifies the build of the device library a PMC traffic figure belongs to: the SHA-256 prefix of the
+    libla_gpu.so in use (hipcc output is reproducible; comments do not change it, any kernel change does)."""
     import hashlib
-    h = hashlib.sha256()
-    for f in ("la_lz4_fast.hip", "la_dev.h"):
-        h.update(open(os.path.join(ROOT, "libarchive_amd", "csrc", f), "rb").read())
-    return h.hexdigest()[:16]
+    from libarchive_amd import _native as N
+    return hashlib.sha256(open(N.GPU_LIB_PATH, "rb").read()).hexdigest()[:16]
 
 
 def build_tiled_stream(torch, la, S, rank, world, unique_mib, total_gib, device):
@@ -491,11 +490,11 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
         if os.path.exists(tpath) and abs(args.gib - 16.0) < 1e-6 and not args.general_only and not args.extra_options:
             rec = json.load(open(tpath))
-            if rec.get("kernel_source_sha16") == kernel_source_id():
+            if rec.get("library_sha16") == kernel_source_id():
                 traffic = rec["lz4_expand_fast_kernel"]["hbm_bytes_per_launch"]
             else:
-                traffic_note = "profiles/r02_traffic.json was measured on another build of the kernel (%s, now %s): not quoted" % (
-                    rec.get("kernel_source_sha16"), kernel_source_id())
+                traffic_note = "profiles/r02_traffic.json was measured on another build of libla_gpu.so (%s, now %s): not quoted" % (
+                    rec.get("library_sha16"), kernel_source_id())
         nl = 4 if (plan.n_blocks >= 32768 and not args.general_only) else 1   # slice launches of the expand kernel per step
         # per-launch algorithmic bytes / per-launch duration (the slices are equal, so this is the ratio of the sums)
         achieved = (C_bytes + U_bytes) / (exp_ms * 1e-3) / 1e9

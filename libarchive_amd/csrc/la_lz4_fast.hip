@@ -57,6 +57,9 @@
  * are not a few stragglers, the whole in-flight set advances one dependency level per look),
  * pulling the table and payload of the block 512 / 1024 / 2048 places ahead towards L2 at the
  * start of the match phase (22.4 / 22.5 / 22.8 from 21.8: the prepass is not waiting for HBM),
+ * the source loads of a match issued right behind its flag look instead of after it (safe: the LDS
+ * serves a wave in order; one round trip per level instead of two, but 24.3 from 21.8 -- the loads of
+ * lanes that are not ready yet are lane-accesses the LDS pipe has no room for),
  * wave-cooperative match copies (four matches per pass
  * through ds_bpermute, 35.1), flag look requested one iteration ahead (28.3),
  * speculative source read behind the flag look (27.6), 8-ary search (26.9 from

@@ -16,9 +16,9 @@ for p in ("fetch","write"):
         for k in acc:
             if "lz4" in k or "scan" in k: res[k][p+"_kb_per_launch"]=acc[k]/cnt[k]; res[k]["launches"]=cnt[k]
 import hashlib
-h=hashlib.sha256()
-for f in ("la_lz4_fast.hip","la_dev.h"): h.update(open("libarchive_amd/csrc/"+f,"rb").read())
-res["kernel_source_sha16"]=h.hexdigest()[:16]
+import os
+lib=os.environ.get("LA_GPU_LIB") or "libarchive_amd/csrc/libla_gpu.so"
+res["library_sha16"]=hashlib.sha256(open(lib,"rb").read()).hexdigest()[:16]	# the build the counters belong to (bench.py compares)
 k=[x for x in res if "lz4_expand_fast_kernel" in x and "false" in x]
 if k:
     r=res[k[0]]
