@@ -74,9 +74,10 @@ int  archive_read_data_into_fd(struct archive *, int fd);			/* archive_read_data
 int  archive_read_close(struct archive *);
 int  archive_read_free(struct archive *);
 
-/* ---- write side: the slice the lz4 write filter needs (host/la_write_lz4.c; archive.h:785-940) ---- */
+/* ---- write side: the slice the lz4 write filter needs (host/la_write_filters.c; archive.h:785-940) ---- */
 struct archive *archive_write_new(void);
 int  archive_write_add_filter_lz4(struct archive *);				/* archive.h:819; archive_write_add_filter_lz4.c:94 */
+int  archive_write_add_filter_gzip(struct archive *);				/* archive.h:816; archive_write_add_filter_gzip.c:98 */
 int  archive_write_set_format_raw(struct archive *);				/* one entry, data passed through */
 int  archive_write_set_filter_option(struct archive *, const char *m, const char *o, const char *v);	/* "lz4", "block-checksum", "1" ... */
 int  archive_write_open_memory(struct archive *, void *buffer, size_t buffSize, size_t *used);

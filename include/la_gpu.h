@@ -278,6 +278,28 @@ uint64_t la_gpu_lz4_compress_workspace_bytes(uint64_t src_bytes, uint32_t block_
 uint64_t la_gpu_lz4_compress_bound(uint64_t src_bytes, uint32_t block_size, uint32_t blocks_per_frame);
 int      la_gpu_lz4_compress(la_gpu_ctx *ctx, const la_lz4c_batch *batch);
 
+/* =====================================================================
+ * gzip compression -- the data plane of the gzip WRITE filter: replaces, for a whole stream per
+ * call, deflate() through zlib, the hand-built header, the CRC32 of the input and the trailer of
+ * libarchive/archive_write_add_filter_gzip.c:201-237, :263-266, :293-345.  d_src[0, src_bytes) is cut into chunks of
+ * chunk_bytes (at most 49152); every chunk becomes one gzip member (fixed-Huffman deflate, or a stored block when
+ * it would not shrink) whose header carries the BGZF-compatible "BC" size subfield.  d_out receives the concatenated
+ * members, *d_out_bytes their size (beyond out_cap nothing is written; la_gpu_gzip_compress_bound() always fits).
+ * ===================================================================== */
+typedef struct la_gzc_batch {
+	const uint8_t *d_src;
+	uint64_t       src_bytes;
+	uint32_t       chunk_bytes;	/* 1 .. 49152 */
+	uint32_t       mtime;		/* MTIME of every member header (0 = none, gzip.c:213-220 writes time(NULL) unless "!timestamp") */
+	uint8_t       *d_out;
+	uint64_t       out_cap;
+	uint64_t      *d_out_bytes;	/* one u64 on the device */
+} la_gzc_batch;
+
+uint64_t la_gpu_gzip_compress_workspace_bytes(uint64_t src_bytes, uint32_t chunk_bytes);
+uint64_t la_gpu_gzip_compress_bound(uint64_t src_bytes, uint32_t chunk_bytes);
+int      la_gpu_gzip_compress(la_gpu_ctx *ctx, const la_gzc_batch *batch);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,6 +67,14 @@ class _Lz4cBatchC(C.Structure):
 LA_LZ4C_BLOCK_SUM, LA_LZ4C_CONTENT_SUM = 1, 2
 
 
+class _GzcBatchC(C.Structure):
+    _fields_ = [
+        ("d_src", C.c_void_p), ("src_bytes", C.c_uint64),
+        ("chunk_bytes", C.c_uint32), ("mtime", C.c_uint32),
+        ("d_out", C.c_void_p), ("out_cap", C.c_uint64), ("d_out_bytes", C.c_void_p),
+    ]
+
+
 class _GzBatchC(C.Structure):
     _fields_ = [
         ("d_src", C.c_void_p), ("src_bytes", C.c_uint64),
@@ -118,6 +126,11 @@ def gpu_lib():
         lib.la_gpu_lz4_workspace_bytes.restype = C.c_uint64
         lib.la_gpu_lz4_decode.argtypes = [C.c_void_p, C.POINTER(_Lz4BatchC)]
         lib.la_gpu_lz4_compress.argtypes = [C.c_void_p, C.POINTER(_Lz4cBatchC)]
+        lib.la_gpu_gzip_compress.argtypes = [C.c_void_p, C.POINTER(_GzcBatchC)]
+        lib.la_gpu_gzip_compress_bound.restype = C.c_uint64
+        lib.la_gpu_gzip_compress_bound.argtypes = [C.c_uint64, C.c_uint32]
+        lib.la_gpu_gzip_compress_workspace_bytes.restype = C.c_uint64
+        lib.la_gpu_gzip_compress_workspace_bytes.argtypes = [C.c_uint64, C.c_uint32]
         lib.la_gpu_lz4_compress_bound.restype = C.c_uint64
         lib.la_gpu_lz4_compress_bound.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
         lib.la_gpu_lz4_compress_workspace_bytes.restype = C.c_uint64
@@ -284,6 +297,9 @@ class GpuContext:
 
     def lz4_compress(self, batch: _Lz4cBatchC):
         self._check(gpu_lib().la_gpu_lz4_compress(self._h, C.byref(batch)), "la_gpu_lz4_compress")
+
+    def gzip_compress(self, batch: _GzcBatchC):
+        self._check(gpu_lib().la_gpu_gzip_compress(self._h, C.byref(batch)), "la_gpu_gzip_compress")
 
     def gzip_decode(self, batch: _GzBatchC):
         self._check(gpu_lib().la_gpu_gzip_decode(self._h, C.byref(batch)), "la_gpu_gzip_decode")

@@ -576,4 +576,34 @@ int la_gpu_lz4_compress(la_gpu_ctx *c, const la_lz4c_batch *bt)
 	return LA_OK;
 }
 
+/* ------------------------------------------------------------------ gzip compression */
+
+uint64_t la_gpu_gzip_compress_bound(uint64_t src_bytes, uint32_t chunk)
+{
+	if (chunk == 0)
+		return 0;
+	const uint64_t nc = (src_bytes + chunk - 1) / chunk;
+	return src_bytes + nc * (18u + 8u + 5u) + 64u;	/* a chunk that does not shrink is stored: 5 bytes of block header */
+}
+
+int la_gpu_gzip_compress(la_gpu_ctx *c, const la_gzc_batch *bt)
+{
+	if (!c || !bt || !bt->d_out_bytes || (bt->src_bytes && (!bt->d_src || !bt->d_out)))
+		return LA_ERR_ARG;
+	if (bt->chunk_bytes == 0 || bt->chunk_bytes > 49152u || (bt->src_bytes + bt->chunk_bytes - 1) / bt->chunk_bytes > 0xFFFFFFFEull)
+		return LA_ERR_ARG;
+	const uint64_t need = la_gpu_gzip_compress_workspace_bytes(bt->src_bytes, bt->chunk_bytes);
+	if (need > c->ws_bytes) {
+		int rc = la_gpu_reserve(c, need);
+		if (rc != LA_OK) return rc;
+	}
+	prof_begin(c);
+	int h = prof_open(c, "gzip_compress", c->stream);
+	la_launch_gzip_compress(c->stream, bt->d_src, bt->src_bytes, bt->chunk_bytes, bt->mtime, bt->d_out, bt->out_cap,
+	    bt->d_out_bytes, (uint8_t *)c->ws);
+	prof_close(c, h, c->stream);
+	HIPCHK(c, hipGetLastError());
+	return LA_OK;
+}
+
 } /* extern "C" */

@@ -377,6 +377,10 @@ void la_launch_lz4_expand_queue_big(hipStream_t s, const uint8_t *d_src, uint64_
 void la_launch_lz4_compress(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes, uint32_t block_size,
     uint32_t bpf, uint32_t flags, uint8_t *d_out, uint64_t out_cap, uint64_t *d_out_bytes, uint8_t *ws);
 
+/* la_deflate_comp.hip */
+void la_launch_gzip_compress(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes, uint32_t chunk, uint32_t mtime,
+    uint8_t *d_out, uint64_t out_cap, uint64_t *d_out_bytes, uint8_t *ws);
+
 /* la_inflate.hip */
 void la_launch_inflate(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
     const la_gz_member *d_members, uint32_t n, uint8_t *d_dst, uint64_t dst_cap, la_gz_result *d_results);

@@ -35,3 +35,24 @@ class GzDevicePlan:
     def results(self):
         self.ctx.sync()
         return self.d_results.cpu().numpy().view(N.GZ_RESULT_DTYPE)[:self.n]
+
+
+def compress_to_members(ctx, d_plain, chunk_bytes=49152, mtime=0):
+    """Device gzip compression (la_gpu_gzip_compress): d_plain is a 1-D uint8 CUDA tensor; returns a uint8 CUDA
+    tensor holding the concatenated gzip members (harness for the tests)."""
+    import torch
+    from . import _native as N
+    n = int(d_plain.numel())
+    cap = int(N.gpu_lib().la_gpu_gzip_compress_bound(n, chunk_bytes))
+    d_out = torch.empty(max(cap, 16), dtype=torch.uint8, device=d_plain.device)
+    d_len = torch.zeros(1, dtype=torch.int64, device=d_plain.device)
+    b = N._GzcBatchC()
+    b.d_src = d_plain.data_ptr() if n else None
+    b.src_bytes = n
+    b.chunk_bytes, b.mtime = chunk_bytes, mtime
+    b.d_out, b.out_cap, b.d_out_bytes = d_out.data_ptr(), cap, d_len.data_ptr()
+    ctx.gzip_compress(b)
+    ctx.sync()
+    total = int(d_len.cpu()[0])
+    assert total <= cap, (total, cap)
+    return d_out[:total]

@@ -1,6 +1,6 @@
 /*
- * la_write_lz4.c -- the lz4 WRITE filter on the device data plane, with the small
- * slice of libarchive's write side it needs to stand alone.
+ * la_write_filters.c -- the lz4 and gzip WRITE filters on the device data plane, with the
+ * small slice of libarchive's write side they need to stand alone.
  *
  * The filter keeps the reference's write-filter vtable and registration
  * (libarchive/archive_write_private.h:46-63 `struct archive_write_filter` {options, open, write,
@@ -17,7 +17,14 @@
  *   - "block-dependence" is refused (the device compresses independent blocks);
  *     "compression-level" 1..9 is accepted and means the one level the device has.
  *
- * The write core below is the minimum the filter needs outside libarchive: archive_write_new,
+ * The gzip filter (archive_write_add_filter_gzip.c:98-137 registration: name "gzip", code ARCHIVE_FILTER_GZIP,
+ * options "compression-level" and "timestamp" :142-167) works the same way on la_gpu_gzip_compress(): the stream
+ * is a sequence of members of at most 48 KiB of input each, every one with the BGZF-compatible size subfield, so
+ * that the read side indexes them without searching (every gzip reader reads concatenated members:
+ * archive_read_support_filter_gzip.c:340-365).  "compression-level" 0..9 is accepted and means the one level the
+ * device has (fixed Huffman codes; chunks that do not shrink are stored).
+ *
+ * The write core below is the minimum the filters need outside libarchive: archive_write_new,
  * _add_filter_lz4, _set_format_raw (one entry, data passed through: archive_write_set_format_raw.c),
  * _set_filter_option, _open_memory / _open_fd, _header, _data, _close, _free.
  */
@@ -26,6 +33,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <unistd.h>
 
 #include "la_read_private.h"
@@ -256,8 +264,12 @@ int archive_write_free(struct archive *_a)
 
 #define LZ4W_BLOCK 65536u
 #define LZ4W_BPF   16u
+#define GZW_CHUNK  49152u
 
-struct lz4w_private {	/* archive_write_add_filter_lz4.c:49-68 */
+struct lz4w_private {	/* archive_write_add_filter_lz4.c:49-68; the gzip filter shares the window machinery */
+	int kind;		/* 0 = lz4, 1 = gzip */
+	int timestamp;		/* gzip: > 0 writes time(NULL) into the member headers (archive_write_add_filter_gzip.c:213-220) */
+	uint32_t mtime;
 	int compression_level;
 	unsigned block_independence:1, block_checksum:1, stream_checksum:1;
 	unsigned block_maximum_size:3;
@@ -301,7 +313,7 @@ static int lz4w_options(struct archive_write_filter *f, const char *key, const c
 
 static int lz4w_gpu_fail(struct archive_write_filter *f, struct lz4w_private *d, const char *what)
 {
-	archive_set_error(f->archive, ARCHIVE_ERRNO_MISC, "lz4 GPU data plane: %s failed: %s", what,
+	archive_set_error(f->archive, ARCHIVE_ERRNO_MISC, "%s GPU data plane: %s failed: %s", d->kind ? "gzip" : "lz4", what,
 	    d->gpu ? la_gpu_last_error(d->gpu) : "no device");
 	return ARCHIVE_FATAL;
 }
@@ -312,7 +324,7 @@ static int lz4w_flush_window(struct archive_write_filter *f, struct lz4w_private
 	if (d->win_len == 0)
 		return ARCHIVE_OK;
 	const uint32_t flags = (d->block_checksum ? LA_LZ4C_BLOCK_SUM : 0) | (d->stream_checksum ? LA_LZ4C_CONTENT_SUM : 0);
-	const uint64_t bound = la_gpu_lz4_compress_bound(d->win_len, LZ4W_BLOCK, LZ4W_BPF);
+	const uint64_t bound = d->kind ? la_gpu_gzip_compress_bound(d->win_len, GZW_CHUNK) : la_gpu_lz4_compress_bound(d->win_len, LZ4W_BLOCK, LZ4W_BPF);
 	if (d->d_in_cap < d->win_len) {
 		if (d->d_in) la_gpu_free(d->gpu, d->d_in);
 		d->d_in = NULL; d->d_in_cap = 0;
@@ -324,7 +336,7 @@ static int lz4w_flush_window(struct archive_write_filter *f, struct lz4w_private
 		if (d->d_out) la_gpu_free(d->gpu, d->d_out);
 		if (d->out) la_gpu_free_host(d->gpu, d->out);
 		d->d_out = NULL; d->out = NULL; d->d_out_cap = d->out_cap = 0;
-		const uint64_t cap = la_gpu_lz4_compress_bound(d->win_cap, LZ4W_BLOCK, LZ4W_BPF);
+		const uint64_t cap = d->kind ? la_gpu_gzip_compress_bound(d->win_cap, GZW_CHUNK) : la_gpu_lz4_compress_bound(d->win_cap, LZ4W_BLOCK, LZ4W_BPF);
 		void *hp = NULL;
 		if (la_gpu_malloc(d->gpu, &d->d_out, cap) != LA_OK || la_gpu_malloc_host(d->gpu, &hp, cap) != LA_OK)
 			return lz4w_gpu_fail(f, d, "output allocation");
@@ -337,9 +349,13 @@ static int lz4w_flush_window(struct archive_write_filter *f, struct lz4w_private
 	bt.d_src = d->d_in; bt.src_bytes = d->win_len;
 	bt.block_size = LZ4W_BLOCK; bt.blocks_per_frame = LZ4W_BPF; bt.flags = flags;
 	bt.d_out = d->d_out; bt.out_cap = d->d_out_cap; bt.d_out_bytes = d->d_len;
+	la_gzc_batch gt;
+	memset(&gt, 0, sizeof(gt));
+	gt.d_src = d->d_in; gt.src_bytes = d->win_len; gt.chunk_bytes = GZW_CHUNK; gt.mtime = d->mtime;
+	gt.d_out = d->d_out; gt.out_cap = d->d_out_cap; gt.d_out_bytes = d->d_len;
 	uint64_t total = 0;
 	if (la_gpu_memcpy_h2d(d->gpu, d->d_in, d->win, d->win_len) != LA_OK ||
-	    la_gpu_lz4_compress(d->gpu, &bt) != LA_OK ||
+	    (d->kind ? la_gpu_gzip_compress(d->gpu, &gt) : la_gpu_lz4_compress(d->gpu, &bt)) != LA_OK ||
 	    la_gpu_memcpy_d2h(d->gpu, &total, d->d_len, sizeof(total)) != LA_OK ||
 	    la_gpu_sync(d->gpu) != LA_OK)
 		return lz4w_gpu_fail(f, d, "compress");
@@ -377,7 +393,7 @@ static int lz4w_open(struct archive_write_filter *f)
 	const char *dev = getenv("LA_GPU_DEVICE"), *wm = getenv("LA_GPU_WRITE_WINDOW_MIB");
 	if (la_gpu_open(dev ? atoi(dev) : 0, &d->gpu) != LA_OK) {
 		archive_set_error(f->archive, ARCHIVE_ERRNO_MISC,
-		    "Can't initialize lz4 GPU data plane (no usable gfx950 device); no CPU fallback is built");
+		    "Can't initialize %s GPU data plane (no usable gfx950 device); no CPU fallback is built", d->kind ? "gzip" : "lz4");
 		return ARCHIVE_FATAL;
 	}
 	d->win_cap = (size_t)(wm && atoi(wm) > 0 ? atoi(wm) : 64) << 20;	/* (a multiple of the 1 MiB frame) */
@@ -385,6 +401,8 @@ static int lz4w_open(struct archive_write_filter *f)
 	if (la_gpu_malloc_host(d->gpu, &hp, d->win_cap) != LA_OK)
 		return lz4w_gpu_fail(f, d, "pinned window allocation");
 	d->win = hp;
+	if (d->kind && d->timestamp >= 0)
+		d->mtime = (uint32_t)time(NULL);
 	f->write = lz4w_write;
 	return ARCHIVE_OK;
 }
@@ -395,7 +413,13 @@ static int lz4w_close(struct archive_write_filter *f)
 	if (d->gpu == NULL)
 		return ARCHIVE_OK;
 	int r = lz4w_flush_window(f, d);
-	if (r == ARCHIVE_OK && !d->wrote_anything) {
+	if (r == ARCHIVE_OK && !d->wrote_anything && d->kind) {
+		/* nothing was written: one member with an empty deflate stream, as zlib's Z_FINISH on no input gives
+		 * the reference (header, 03 00, crc 0, isize 0) */
+		const uint8_t m[20] = { 0x1f, 0x8b, 8, 0, (uint8_t)d->mtime, (uint8_t)(d->mtime >> 8), (uint8_t)(d->mtime >> 16),
+		    (uint8_t)(d->mtime >> 24), 0, 3, 0x03, 0x00, 0, 0, 0, 0, 0, 0, 0, 0 };
+		r = __archive_write_filter(f->next_filter, m, sizeof(m));
+	} else if (r == ARCHIVE_OK && !d->wrote_anything) {
 		/* nothing was written: one empty frame (header, EndMark, checksum of nothing), as the
 		 * reference's close does (archive_write_add_filter_lz4.c:300-330) */
 		uint8_t h[15];
@@ -454,5 +478,44 @@ int archive_write_add_filter_lz4(struct archive *_a)
 	f->free = lz4w_free;
 	f->code = ARCHIVE_FILTER_LZ4;
 	f->name = "lz4";
+	return ARCHIVE_OK;
+}
+
+/* ------------------------------------------------------------------ the gzip write filter */
+
+static int gzw_options(struct archive_write_filter *f, const char *key, const char *value)
+{
+	struct lz4w_private *d = f->data;
+	if (strcmp(key, "compression-level") == 0) {	/* archive_write_add_filter_gzip.c:147-153 */
+		if (value == NULL || !(value[0] >= '0' && value[0] <= '9') || value[1] != '\0')
+			return ARCHIVE_WARN;
+		d->compression_level = value[0] - '0';	/* (the device has one level) */
+		return ARCHIVE_OK;
+	}
+	if (strcmp(key, "timestamp") == 0) {		/* :154-157 */
+		d->timestamp = (value == NULL) ? -1 : 1;
+		return ARCHIVE_OK;
+	}
+	return ARCHIVE_WARN;
+}
+
+int archive_write_add_filter_gzip(struct archive *_a)
+{
+	struct archive_write_filter *f = __archive_write_allocate_filter(_a);
+	struct lz4w_private *d = calloc(1, sizeof(*d));
+	if (f == NULL || d == NULL) {
+		free(d);
+		archive_set_error(_a, ENOMEM, "Out of memory");
+		return ARCHIVE_FATAL;
+	}
+	d->kind = 1;
+	d->compression_level = 6;	/* Z_DEFAULT_COMPRESSION in the reference; informational here */
+	f->data = d;
+	f->options = gzw_options;
+	f->open = lz4w_open;
+	f->close = lz4w_close;
+	f->free = lz4w_free;
+	f->code = ARCHIVE_FILTER_GZIP;
+	f->name = "gzip";
 	return ARCHIVE_OK;
 }

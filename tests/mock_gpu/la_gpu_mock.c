@@ -239,3 +239,36 @@ int la_gpu_lz4_compress(la_gpu_ctx *c, const la_lz4c_batch *bt)
 	*bt->d_out_bytes = o;
 	return LA_OK;
 }
+
+/* gzip compression stand-in: every chunk becomes one member with a STORED deflate block */
+uint64_t la_gpu_gzip_compress_workspace_bytes(uint64_t s, uint32_t c) { (void)s; (void)c; return 0; }
+uint64_t la_gpu_gzip_compress_bound(uint64_t src_bytes, uint32_t chunk)
+{
+	if (chunk == 0) return 0;
+	return src_bytes + ((src_bytes + chunk - 1) / chunk) * (18u + 8u + 5u) + 64u;
+}
+int la_gpu_gzip_compress(la_gpu_ctx *c, const la_gzc_batch *bt)
+{
+	(void)c;
+	if (!bt || bt->chunk_bytes == 0 || bt->chunk_bytes > 49152u)
+		return LA_ERR_ARG;
+	uint64_t o = 0;
+	const uint64_t nc = (bt->src_bytes + bt->chunk_bytes - 1) / bt->chunk_bytes;
+	for (uint64_t i = 0; i < nc; i++) {
+		const uint64_t so = i * bt->chunk_bytes;
+		const uint32_t n = (uint32_t)(bt->src_bytes - so < bt->chunk_bytes ? bt->src_bytes - so : bt->chunk_bytes);
+		const uint32_t total = 18u + 5u + n + 8u;
+		if (o + total > bt->out_cap) return LA_ERR_ARG;
+		uint8_t *h = bt->d_out + o;
+		h[0] = 0x1f; h[1] = 0x8b; h[2] = 8; h[3] = 4; mock_le32(h + 4, bt->mtime); h[8] = 0; h[9] = 3;
+		h[10] = 6; h[11] = 0; h[12] = 'B'; h[13] = 'C'; h[14] = 2; h[15] = 0;
+		h[16] = (uint8_t)(total - 1); h[17] = (uint8_t)((total - 1) >> 8);
+		h[18] = 1; h[19] = (uint8_t)n; h[20] = (uint8_t)(n >> 8); h[21] = (uint8_t)~n; h[22] = (uint8_t)(~n >> 8);
+		memcpy(h + 23, bt->d_src + so, n);
+		mock_le32(h + 23 + n, orc_crc32(0, bt->d_src + so, n));
+		mock_le32(h + 27 + n, n);
+		o += total;
+	}
+	*bt->d_out_bytes = o;
+	return LA_OK;
+}

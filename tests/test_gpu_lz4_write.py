@@ -1,5 +1,5 @@
 """The lz4 WRITE filter on the device data plane through the archive_write_* slice
-(host/la_write_lz4.c): archive_write_new -> add_filter_lz4 -> set_format_raw -> open_memory -> header ->
+(host/la_write_filters.c): archive_write_new -> add_filter_lz4 -> set_format_raw -> open_memory -> header ->
 data (in pieces) -> close.  What it writes must read back as the input through the reference-equivalent
 reader (the oracle), through this repository's own read path (la_api.cat: bid, filter, raw format), and must
 carry the options in its frame descriptors."""
@@ -22,7 +22,7 @@ def _lib():
 
 def _lib_setup(lib):
     lib.archive_write_new.restype = C.c_void_p
-    for f in ("archive_write_add_filter_lz4", "archive_write_set_format_raw", "archive_write_close", "archive_write_free"):
+    for f in ("archive_write_add_filter_lz4", "archive_write_add_filter_gzip", "archive_write_set_format_raw", "archive_write_close", "archive_write_free"):
         getattr(lib, f).argtypes = [C.c_void_p]
     lib.archive_write_set_filter_option.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p]
     lib.archive_write_open_memory.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
@@ -34,13 +34,13 @@ def _lib_setup(lib):
     return lib
 
 
-def write_lz4(data, options=(), piece=None, cap=None):
+def write_lz4(data, options=(), piece=None, cap=None, codec="lz4"):
     lib = _lib()
     a = lib.archive_write_new()
-    assert lib.archive_write_add_filter_lz4(a) == ARCHIVE_OK
+    assert getattr(lib, "archive_write_add_filter_" + codec)(a) == ARCHIVE_OK
     assert lib.archive_write_set_format_raw(a) == ARCHIVE_OK
     for k, v in options:
-        rc = lib.archive_write_set_filter_option(a, b"lz4", k.encode(), None if v is None else v.encode())
+        rc = lib.archive_write_set_filter_option(a, codec.encode(), k.encode(), None if v is None else v.encode())
         if rc != ARCHIVE_OK:
             err = lib.archive_error_string(a)
             lib.archive_write_free(a)
@@ -96,3 +96,28 @@ def test_write_filter_options_and_errors(gpu_ctx):
     assert rc == ARCHIVE_FAILED and "Undefined option" in err
     rc, err = write_lz4(bytes(200000), (), None, cap=100)     # the client's buffer is too small
     assert rc == ARCHIVE_FATAL and err == "Buffer exhausted"
+
+
+def test_gzip_write_filter_round_trips(gpu_ctx, monkeypatch):
+    """archive_write_add_filter_gzip on the device data plane: what it writes reads back through zlib's gzip reader,
+    the oracle's gzip filter and this repository's read path; options as the reference's (timestamp, compression-level)."""
+    import gzip
+    import io
+    import struct
+    monkeypatch.setenv("LA_GPU_WRITE_WINDOW_MIB", "2")
+    rnd = random.Random(10)
+    words = [rnd.randbytes(rnd.randint(2, 10)) for _ in range(200)]
+    text = b"".join(rnd.choice(words) for _ in range(1200000))[:5 * 1024 * 1024 + 77]
+    for data, piece in ((b"", None), (b"z", None), (text[:50000], 999), (text, 65536 + 3), (rnd.randbytes(200000), None), (bytes(2 << 20), 8192)):
+        for options in ((), (("timestamp", None),), (("compression-level", "9"),)):
+            rc, img = write_lz4(data, options, piece, codec="gzip")
+            assert rc == ARCHIVE_OK and img[:3] == b"\x1f\x8b\x08"
+            mtime = struct.unpack_from("<I", img, 4)[0]
+            assert (mtime == 0) == (("timestamp", None) in options)
+            assert gzip.GzipFile(fileobj=io.BytesIO(img)).read() == data
+            out, res = O.gzip_stream_decode(img, len(data) + 64)
+            assert (res.rc, res.errmsg) == (0, b"") and out.tobytes() == data
+            r = la_api.cat(img)
+            assert r.filters[0] == (1, "gzip") and r.data == data
+    rc, err = write_lz4(b"abc", (("no-such-option", "1"),), codec="gzip")
+    assert rc == ARCHIVE_FAILED and "Undefined option" in err

@@ -84,6 +84,7 @@ def test_write_filter_host_logic_on_the_mock(gpu_ctx, monkeypatch):
             rc, img = W.write_lz4(data, opts, rnd.choice([None, 4097]))
             assert rc == 0 and la_api.cat(img).data == data
     W.test_write_filter_options_and_errors(None)
+    W.test_gzip_write_filter_round_trips(None, monkeypatch)
 
 
 def test_mock_library_is_not_the_product(gpu_ctx):
