@@ -109,6 +109,9 @@ int    la_gz_index_build2(const uint8_t *img, uint64_t len, int at_eof, uint32_t
 #define LA_GZ_INDEX_STRICT 1u
 int    la_gz_index_build3(const uint8_t *img, uint64_t len, int at_eof, uint32_t first_skip,
            uint32_t first_cap, uint32_t flags, la_gz_index *idx);
+/* out_budget: stop indexing once the members taken ask for this many decoded bytes (0 = no bound) */
+int    la_gz_index_build4(const uint8_t *img, uint64_t len, int at_eof, uint32_t first_skip,
+           uint32_t first_cap, uint32_t flags, uint64_t out_budget, la_gz_index *idx);
 void   la_gz_index_free(la_gz_index *idx);
 
 /* ---- hash drop-ins (host/la_hash_dropin.c) ----

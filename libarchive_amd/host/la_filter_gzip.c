@@ -55,6 +55,7 @@ struct gzip_private {
 	size_t h_res_cap;
 	uint64_t total_out;	/* bytes decoded so far (delivered + carry) */
 	uint32_t hint_skip, hint_cap;
+	uint64_t out_budget;	/* decoded bytes (output slots) one window may ask for: LA_GPU_OUT_BUDGET_MIB, default 4096 */
 	int strict;
 	int trace;
 	int loose;		/* the stream's headers carry unusual XFL / OS bytes: index without LA_GZ_INDEX_STRICT */
@@ -158,6 +159,8 @@ static int gzip_bidder_init(struct archive_read_filter *self)
 	const char *dev = getenv("LA_GPU_DEVICE"), *bm = getenv("LA_GPU_BATCH_MIB"), *sv = getenv("LA_GZIP_STRICT");
 	st->batch_bytes = (size_t)(bm && atoi(bm) > 0 ? atoi(bm) : 256) << 20;
 	st->strict = sv && atoi(sv) != 0;
+	const char *ob = getenv("LA_GPU_OUT_BUDGET_MIB");
+	st->out_budget = (uint64_t)(ob && atoi(ob) > 0 ? atoi(ob) : 4096) << 20;
 	st->trace = getenv("LA_GPU_TRACE") != NULL && atoi(getenv("LA_GPU_TRACE")) != 0;
 	int rc = la_gpu_open(dev ? atoi(dev) : 0, &st->gpu);
 	if (rc != LA_OK) {
@@ -505,8 +508,8 @@ static int gz_prepare(struct archive_read_filter *self, struct gzip_private *st)
 	    (gz_grow_dev(st, &st->d_src, &st->d_src_cap, st->stage_len + 64) < 0 ||
 	     la_gpu_memcpy_h2d(st->gpu, st->d_src, st->stage, st->stage_len) != LA_OK))
 		return gz_gpu_fail(self, st, "host to device copy");
-	if (la_gz_index_build3(st->stage, st->stage_len, st->upstream_eof, st->hint_skip, st->hint_cap,
-	    st->loose ? 0 : LA_GZ_INDEX_STRICT, &st->idx) != 0) {
+	if (la_gz_index_build4(st->stage, st->stage_len, st->upstream_eof, st->hint_skip, st->hint_cap,
+	    st->loose ? 0 : LA_GZ_INDEX_STRICT, st->out_budget, &st->idx) != 0) {
 		archive_set_error(&self->archive->archive, ENOMEM, "Can't allocate data for gzip decompression");
 		return ARCHIVE_FATAL;
 	}

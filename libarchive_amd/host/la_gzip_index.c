@@ -181,6 +181,16 @@ int la_gz_index_build2(const uint8_t *img, uint64_t len, int at_eof, uint32_t fi
 int la_gz_index_build3(const uint8_t *img, uint64_t len, int at_eof, uint32_t first_skip,
     uint32_t first_cap, uint32_t flags, la_gz_index *x)
 {
+	return la_gz_index_build4(img, len, at_eof, first_skip, first_cap, flags, 0, x);
+}
+
+/* out_budget != 0 bounds the window by DECODED bytes too (sum of the members' output slots): a window of
+ * highly compressible members would otherwise claim up to 1032 x its size in slab.  The walker stops in front
+ * of the member that would pass the budget (at least one member is always taken) and reports
+ * LA_END_NEED_MORE: the rest of the window is the next window's. */
+int la_gz_index_build4(const uint8_t *img, uint64_t len, int at_eof, uint32_t first_skip,
+    uint32_t first_cap, uint32_t flags, uint64_t out_budget, la_gz_index *x)
+{
 	const int strict = (flags & LA_GZ_INDEX_STRICT) != 0;
 	uint64_t pos = 0, out = 0;
 	memset(x, 0, sizeof(*x));
@@ -188,6 +198,10 @@ int la_gz_index_build3(const uint8_t *img, uint64_t len, int at_eof, uint32_t fi
 
 	for (;;) {
 		x->consumed = pos;
+		if (out_budget && x->n > 0 && out >= out_budget) {
+			x->end_kind = LA_END_NEED_MORE;
+			break;
+		}
 		la_gz_header h;
 		size_t hlen = la_gz_header_parse(img + pos, (size_t)(len - pos), &h);
 		if (hlen == 0) {

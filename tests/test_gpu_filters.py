@@ -467,3 +467,22 @@ def test_gzip_bid_only_indexed_switch(gpu_ctx, monkeypatch):
     assert r.filters[0][1] != "gzip" and r.data == ordinary
     r = la_api.cat(indexed)
     assert r.filters[0] == (1, "gzip") and r.data == plain
+
+
+def test_gzip_window_bounded_by_decoded_bytes(gpu_ctx, monkeypatch):
+    """Highly compressible members: one window of compressed bytes would claim far more slab than is sane (deflate
+    expands up to 1032 x).  LA_GPU_OUT_BUDGET_MIB bounds a window by the decoded bytes its members ask for; the rest of
+    the window is decoded by the following windows.  Bytes, rc and message stay the reference's."""
+    monkeypatch.setenv("LA_GPU_OUT_BUDGET_MIB", "1")
+    rnd = random.Random(808)
+    members = [S.gz_member(bytes(rnd.choice([65536, 200000, 10]))) for _ in range(60)] + [S.gz_member(b"tail " * 1000)]
+    img = b"".join(members)
+    plain_len = sum(len(__import__("zlib").decompress(m, 31)) for m in members)
+    assert len(img) < 100000 and plain_len > 3 << 20
+    for variant in range(3):
+        m = img if variant == 0 else img[:len(img) // 2] if variant == 1 else img[:700] + b"\x00" + img[701:]
+        ref, _ = oracle_tuple(m, "gzip")
+        r = la_api.cat(m, read_size=rnd.choice([None, 4096]))
+        assert la_api.as_reference_tuple(r) == ref, variant
+        if variant == 0:
+            assert len(ref[0]) == plain_len and len(r.block_sizes) >= 4     # several bounded windows

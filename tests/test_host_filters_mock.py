@@ -48,6 +48,7 @@ from test_gpu_filters import (  # noqa: E402,F401
     test_gzip_single_member_across_windows,
     test_lz4_window_bounded_by_decoded_bytes,
     test_gzip_bid_only_indexed_switch,
+    test_gzip_window_bounded_by_decoded_bytes,
 )
 from test_gpu_tar import (  # noqa: E402,F401
     test_reference_tar_fixtures_list_like_the_reference_tests,
