@@ -402,15 +402,15 @@ int la_gpu_lz4_decode(la_gpu_ctx *c, const la_lz4_batch *bt)
 	h = prof_open(c, fast ? "lz4_expand_general" : "lz4_expand", sx);
 	la_launch_lz4_expand_general(sx, bt->d_src, bt->src_bytes, bt->d_blocks, n, bt->d_dst,
 	    bt->dst_cap, bt->d_dst_off, bt->d_out_len, bt->d_block_status, w.nseq,
-	    fast ? 0xFFFFFFFEu : 0u,	/* the LDS-window kernel takes every eligible block that got a table */
-	    bt->hist_len);
+	    fast ? 0xFFFFFFFEu : 0u,	/* the LDS-window kernel takes every eligible block that got a table ... */
+	    bt->hist_len, LA_LZ4_LONG_SEQ_BYTES);	/* ... except blocks of few long sequences (la_dev.h) */
 	prof_close(c, h, sx);
 	if (fast) {
 		/* eligible blocks with more sequences than one LDS segment: classified on the device,
 		 * shared out over a small grid (a no-op launch when there are none) */
 		h = prof_open(c, "lz4_expand_big", sx);
 		(queue ? la_launch_lz4_expand_queue_big : la_launch_lz4_expand_fast_big)(sx, bt->d_src, bt->src_bytes, bt->d_blocks, n, bt->d_dst, bt->dst_cap,
-		    bt->d_dst_off, bt->d_out_len, bt->d_block_status, w.nseq, w.table, w.table_off, w.big);
+		    bt->d_dst_off, bt->d_out_len, bt->d_block_status, w.nseq, w.table, w.table_off, w.big, LA_LZ4_LONG_SEQ_BYTES);
 		prof_close(c, h, sx);
 	}
 	const uint32_t nsl = (fast && n >= 4u * 8192u) ? 4u : 1u;
@@ -422,7 +422,7 @@ int la_gpu_lz4_decode(la_gpu_ctx *c, const la_lz4_batch *bt)
 			h = prof_open(c, "lz4_expand", sx);
 			(queue ? la_launch_lz4_expand_queue : la_launch_lz4_expand_fast)(sx, bt->d_src, bt->src_bytes, bt->d_blocks + first, last - first, bt->d_dst,
 			    bt->dst_cap, bt->d_dst_off + first, bt->d_out_len + first, bt->d_block_status + first,
-			    w.nseq + first, w.table, w.table_off + first);
+			    w.nseq + first, w.table, w.table_off + first, LA_LZ4_LONG_SEQ_BYTES);
 			prof_close(c, h, sx);
 		}
 		if (bt->n_frames && verify) {
@@ -514,10 +514,10 @@ int la_gpu_gzip_decode(la_gpu_ctx *c, const la_gz_batch *bt)
 		prof_close(c, h, s);
 		h = prof_open(c, "inflate_expand", s);
 		la_launch_lz4_expand_fast(s, E.lit, (uint64_t)n * 65536u, E.blocks, n, bt->d_dst, bt->dst_cap,
-		    E.dst_off, E.out_len, E.xstatus, E.nseq, E.table, E.table_off);
+		    E.dst_off, E.out_len, E.xstatus, E.nseq, E.table, E.table_off, 0u);
 		/* members with more matches than one LDS segment holds */
 		la_launch_lz4_expand_fast_big(s, E.lit, (uint64_t)n * 65536u, E.blocks, n, bt->d_dst, bt->dst_cap,
-		    E.dst_off, E.out_len, E.xstatus, E.nseq, E.table, E.table_off, gz_big);
+		    E.dst_off, E.out_len, E.xstatus, E.nseq, E.table, E.table_off, gz_big, 0u);
 		prof_close(c, h, s);
 		/* members the LDS-window kernel cannot take: decoded in place */
 		h = prof_open(c, "inflate", s);

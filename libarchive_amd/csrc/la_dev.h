@@ -337,6 +337,17 @@ __host__ __device__ __forceinline__ bool la_lz4_fast_eligible(const la_lz4_block
 	return !(b.flags & (LA_LZ4B_STORED | LA_LZ4B_DEPENDENT)) && b.dst_cap <= 65536u && b.src_len <= 65536u;
 }
 
+/* Blocks made of few, long sequences (long runs, big repeats: on average LA_LZ4_LONG_SEQ_BYTES decoded bytes per
+ * sequence or more) go to the wave-wide general kernel even when the LDS-window kernels could take them: one lane per
+ * match copies a 64 KiB run at the speed of one lane (10 GB/s on blocks of zeros), the general kernel's wave-wide
+ * copies reach 250 GB/s on them (tools/measure_long_matches.py).  thr = 0 switches the routing off (the deflate
+ * front end has no general kernel behind it).  The same predicate is used on both sides. */
+#define LA_LZ4_LONG_SEQ_BYTES 512u
+__host__ __device__ __forceinline__ bool la_lz4_long_sequences(uint32_t nseq, uint32_t out_len, uint32_t thr)
+{
+	return thr != 0 && nseq != 0xFFFFFFFFu && (uint64_t)nseq * thr <= out_len;
+}
+
 void la_launch_lz4_table_caps(hipStream_t s, const la_lz4_block *d_blocks, uint32_t n, uint32_t *d_caps);
 void la_launch_lz4_parse(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
     const la_lz4_block *d_blocks, uint32_t n, uint32_t *d_out_len, uint32_t *d_nseq,
@@ -351,27 +362,27 @@ void la_launch_lz4_parse_staged(hipStream_t s, const uint8_t *d_src, uint64_t sr
 void la_launch_lz4_expand_general(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
     const la_lz4_block *d_blocks, uint32_t n, uint8_t *d_dst, uint64_t dst_cap,
     const uint64_t *d_dst_off, const uint32_t *d_out_len, const uint32_t *d_status,
-    const uint32_t *d_nseq, uint32_t fast_max_seq /* 0: take every block */, uint32_t hist_len);
+    const uint32_t *d_nseq, uint32_t fast_max_seq /* 0: take every block */, uint32_t hist_len, uint32_t long_thr);
 void la_launch_lz4_expand_fast(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
     const la_lz4_block *d_blocks, uint32_t n, uint8_t *d_dst, uint64_t dst_cap,
     const uint64_t *d_dst_off, const uint32_t *d_out_len, uint32_t *d_status,
-    const uint32_t *d_nseq, const la_lz4_seq *d_table, const uint64_t *d_table_off);
+    const uint32_t *d_nseq, const la_lz4_seq *d_table, const uint64_t *d_table_off, uint32_t long_thr);
 void la_launch_lz4_expand_fast_big(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
     const la_lz4_block *d_blocks, uint32_t n, uint8_t *d_dst, uint64_t dst_cap,
     const uint64_t *d_dst_off, const uint32_t *d_out_len, uint32_t *d_status,
     const uint32_t *d_nseq, const la_lz4_seq *d_table, const uint64_t *d_table_off,
-    uint32_t *d_big /* n + 1 words */);
+    uint32_t *d_big /* n + 1 words */, uint32_t long_thr);
 
 /* la_lz4_fastq.hip: the same contract as the two launches above, queue generation */
 void la_launch_lz4_expand_queue(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
     const la_lz4_block *d_blocks, uint32_t n, uint8_t *d_dst, uint64_t dst_cap,
     const uint64_t *d_dst_off, const uint32_t *d_out_len, uint32_t *d_status,
-    const uint32_t *d_nseq, const la_lz4_seq *d_table, const uint64_t *d_table_off);
+    const uint32_t *d_nseq, const la_lz4_seq *d_table, const uint64_t *d_table_off, uint32_t long_thr);
 void la_launch_lz4_expand_queue_big(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
     const la_lz4_block *d_blocks, uint32_t n, uint8_t *d_dst, uint64_t dst_cap,
     const uint64_t *d_dst_off, const uint32_t *d_out_len, uint32_t *d_status,
     const uint32_t *d_nseq, const la_lz4_seq *d_table, const uint64_t *d_table_off,
-    uint32_t *d_big /* n + 1 words */);
+    uint32_t *d_big /* n + 1 words */, uint32_t long_thr);
 
 /* la_lz4_comp.hip */
 void la_launch_lz4_compress(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes, uint32_t block_size,

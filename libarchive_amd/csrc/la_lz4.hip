@@ -352,7 +352,8 @@ __device__ void lz4_expand_block_wave(const uint8_t *s, uint32_t src_len, const 
 __global__ __launch_bounds__(256) void lz4_expand_general_kernel(const uint8_t *__restrict__ src,
     uint64_t src_bytes, const la_lz4_block *__restrict__ blocks, uint32_t n, uint8_t *dst,
     uint64_t dst_cap, const uint64_t *__restrict__ dst_off, const uint32_t *__restrict__ out_len,
-    const uint32_t *__restrict__ status, const uint32_t *__restrict__ nseq, uint32_t fast_max_seq, uint32_t hist_len)
+    const uint32_t *__restrict__ status, const uint32_t *__restrict__ nseq, uint32_t fast_max_seq, uint32_t hist_len,
+    uint32_t long_thr)
 {
 	int lane = threadIdx.x & 63;
 	uint32_t i = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(256) void lz4_expand_general_kernel(const uint8_t *
 		/* never write past the slab, whatever the tables say; blocks the LDS-window
 		 * kernel takes are skipped here (same predicate on both sides) */
 		if (status[i] == LA_ST_OK && olen > 0 && dst_off[i] + olen <= dst_cap &&
-		    !(fast_max_seq && la_lz4_fast_eligible(b) && nseq[i] <= fast_max_seq)) {
+		    !(fast_max_seq && la_lz4_fast_eligible(b) && nseq[i] <= fast_max_seq && !la_lz4_long_sequences(nseq[i], olen, long_thr))) {
 			const uint8_t *s = src + b.src_off;
 			if (b.flags & LA_LZ4B_STORED) {
 				/* stored block (lz4.c:530-552): bytes up to the slab's 16-byte grid one by one,
@@ -412,9 +413,9 @@ __global__ __launch_bounds__(256) void lz4_expand_general_kernel(const uint8_t *
 void la_launch_lz4_expand_general(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
     const la_lz4_block *d_blocks, uint32_t n, uint8_t *d_dst, uint64_t dst_cap,
     const uint64_t *d_dst_off, const uint32_t *d_out_len, const uint32_t *d_status,
-    const uint32_t *d_nseq, uint32_t fast_max_seq, uint32_t hist_len)
+    const uint32_t *d_nseq, uint32_t fast_max_seq, uint32_t hist_len, uint32_t long_thr)
 {
 	if (n == 0) return;
 	hipLaunchKernelGGL(lz4_expand_general_kernel, dim3((n + 3) / 4), dim3(256), 0, s,
-	    d_src, src_bytes, d_blocks, n, d_dst, dst_cap, d_dst_off, d_out_len, d_status, d_nseq, fast_max_seq, hist_len);
+	    d_src, src_bytes, d_blocks, n, d_dst, dst_cap, d_dst_off, d_out_len, d_status, d_nseq, fast_max_seq, hist_len, long_thr);
 }

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(FAST_THREADS, FAST_MIN_WAVES) void lz4_expand_fast_
     const uint32_t *__restrict__ out_len, uint32_t *status_out,
     const uint32_t *__restrict__ nseq, const la_lz4_seq *__restrict__ table,
     const uint64_t *__restrict__ table_off, const uint32_t *__restrict__ big_list,
-    const uint32_t *__restrict__ big_count)
+    const uint32_t *__restrict__ big_count, uint32_t long_thr)
 {
 	const uint32_t *status = status_out;
 	__shared__ __attribute__((aligned(16))) uint8_t win[16 + 65536 + 96];	/* 16 headroom (literal stores may start 3 bytes early) + 16 alignment shift + slack for over-reads */
@@ -188,8 +188,8 @@ __global__ __launch_bounds__(FAST_THREADS, FAST_MIN_WAVES) void lz4_expand_fast_
 	const uint64_t doff = dst_off[bi];
 	/* same predicate as the general kernel's skip test (0xFFFFFFFF: the block has no table) */
 	if (status[bi] != LA_ST_OK || olen == 0 || !la_lz4_fast_eligible(b) || ns_all == 0xFFFFFFFFu ||
-	    doff + olen > dst_cap)
-		return;
+	    doff + olen > dst_cap || la_lz4_long_sequences(ns_all, olen, long_thr))
+		return;		/* (few long sequences: the general kernel takes the block, la_dev.h) */
 
 	STAMP(0);
 	const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -628,13 +628,14 @@ __global__ __launch_bounds__(FAST_THREADS, FAST_MIN_WAVES) void lz4_expand_fast_
 /* blocks the SEG launch must take: eligible, with a table, more than MAXSEQ sequences */
 __global__ __launch_bounds__(256) void lz4_classify_kernel(const la_lz4_block *__restrict__ blocks, uint32_t n,
     const uint32_t *__restrict__ status, const uint32_t *__restrict__ nseq, uint32_t *__restrict__ big_list,
-    uint32_t *__restrict__ big_count)
+    uint32_t *__restrict__ big_count, const uint32_t *__restrict__ out_len, uint32_t long_thr)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n)
 		return;
 	const uint32_t ns = nseq[i];
-	if (ns != 0xFFFFFFFFu && ns > LA_LZ4_FAST_MAXSEQ && status[i] == LA_ST_OK && la_lz4_fast_eligible(blocks[i]))
+	if (ns != 0xFFFFFFFFu && ns > LA_LZ4_FAST_MAXSEQ && status[i] == LA_ST_OK && la_lz4_fast_eligible(blocks[i]) &&
+	    !la_lz4_long_sequences(ns, out_len[i], long_thr))
 		big_list[atomicAdd(big_count, 1u)] = i;
 }
 
@@ -649,12 +650,12 @@ extern "C" int la_diag_set_stamps(void *d_buf)
 void la_launch_lz4_expand_fast(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
     const la_lz4_block *d_blocks, uint32_t n, uint8_t *d_dst, uint64_t dst_cap,
     const uint64_t *d_dst_off, const uint32_t *d_out_len, uint32_t *d_status,
-    const uint32_t *d_nseq, const la_lz4_seq *d_table, const uint64_t *d_table_off)
+    const uint32_t *d_nseq, const la_lz4_seq *d_table, const uint64_t *d_table_off, uint32_t long_thr)
 {
 	if (n == 0) return;
 	hipLaunchKernelGGL((lz4_expand_fast_kernel<LA_LZ4_FAST_MAXSEQ, false>), dim3(n), dim3(FAST_THREADS), 0, s,
 	    d_src, src_bytes, d_blocks, n, d_dst, dst_cap, d_dst_off, d_out_len, d_status, d_nseq,
-	    d_table, d_table_off, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
+	    d_table, d_table_off, (const uint32_t *)nullptr, (const uint32_t *)nullptr, long_thr);
 }
 
 /* blocks with more than LA_LZ4_FAST_MAXSEQ sequences, over the WHOLE table: classify + a small
@@ -662,14 +663,14 @@ void la_launch_lz4_expand_fast(hipStream_t s, const uint8_t *d_src, uint64_t src
 void la_launch_lz4_expand_fast_big(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
     const la_lz4_block *d_blocks, uint32_t n, uint8_t *d_dst, uint64_t dst_cap,
     const uint64_t *d_dst_off, const uint32_t *d_out_len, uint32_t *d_status,
-    const uint32_t *d_nseq, const la_lz4_seq *d_table, const uint64_t *d_table_off, uint32_t *d_big)
+    const uint32_t *d_nseq, const la_lz4_seq *d_table, const uint64_t *d_table_off, uint32_t *d_big, uint32_t long_thr)
 {
 	if (n == 0) return;
 	(void)hipMemsetAsync(d_big, 0, sizeof(uint32_t), s);
 	hipLaunchKernelGGL(lz4_classify_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_blocks, n, d_status, d_nseq,
-	    d_big + 1, d_big);
+	    d_big + 1, d_big, d_out_len, long_thr);
 	const uint32_t grid = n < 1024u ? n : 1024u;
 	hipLaunchKernelGGL((lz4_expand_fast_kernel<LA_LZ4_FAST_MAXSEQ, true>), dim3(grid), dim3(FAST_THREADS), 0, s,
 	    d_src, src_bytes, d_blocks, n, d_dst, dst_cap, d_dst_off, d_out_len, d_status, d_nseq,
-	    d_table, d_table_off, (const uint32_t *)(d_big + 1), (const uint32_t *)d_big);
+	    d_table, d_table_off, (const uint32_t *)(d_big + 1), (const uint32_t *)d_big, long_thr);
 }

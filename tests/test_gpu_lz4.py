@@ -237,3 +237,28 @@ def test_length_extension_run_cannot_wrap_the_sum(gpu_ctx):
         ref, res = O.lz4_stream_decode(img, 1 << 24)
         assert (ref.tobytes(), res.rc, res.errmsg) == (b"", -30, b"lz4 decompression failed")
         assert gpu_decode(gpu_ctx, img) == (b"", -30, "lz4 decompression failed")
+
+
+def test_blocks_of_runs_long_and_medium(gpu_ctx):
+    """Overlapping matches (offset < length).  Blocks of FEW LONG sequences (a 64 KiB run, long repeats) are routed to the
+    wave-wide general kernel (la_dev.h, la_lz4_long_sequences); blocks of MANY MEDIUM runs stay with the LDS-window
+    kernels, whose two generations copy them differently (owner lane byte by byte / period doubling in dense passes).
+    Every variant must give the oracle's bytes."""
+    rnd = random.Random(606)
+    blocks = []
+    for k in range(24):
+        kind = k % 4
+        if kind == 0:
+            d = bytes([k]) * 65536                                   # one run
+        elif kind == 1:
+            d = (bytes(rnd.randbytes(rnd.randint(1, 9))) * 40000)[:65536]     # one long repeat of a short period
+        elif kind == 2:
+            d = b"".join(bytes([rnd.getrandbits(8)]) * rnd.randint(60, 400) for _ in range(400))[:65536]    # many medium runs
+        else:
+            d = b"".join(rnd.randbytes(rnd.randint(1, 5)) * rnd.randint(20, 120) + rnd.randbytes(rnd.randint(0, 30))
+                         for _ in range(500))[:65536]                # medium repeats of periods 1..5 with literals between
+        blocks.append((d, S.lz4_block(S.lz4_compress_block(d), bsum=True)))
+    img, plain = S.lz4_frame(blocks, flg=0x74)
+    ref, res = O.lz4_stream_decode(img, len(plain) + 16)
+    assert res.rc == 0 and ref.tobytes() == plain
+    assert gpu_decode(gpu_ctx, img) == (plain, 0, "")
