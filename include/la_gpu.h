@@ -173,6 +173,8 @@ typedef struct la_batch_summary {
 #define LA_LZ4_OPT_EXPAND_QUEUE 8u	/* second implementation of the LDS-window expand step (la_lz4_fastq.hip: byte-validity
 					 * bitmap, shared ready queue, aligned LDS copies); same results, kept as a cross-check
 					 * and for blocks of long overlapping matches */
+#define LA_LZ4_OPT_EXPAND_WIDE 32u	/* third implementation of the expand step (la_lz4_wide.hip: one wave per block, one lane per
+					 * sequence, the output window in the decoded slab itself instead of LDS); same results */
 
 typedef struct la_lz4_batch {
 	const uint8_t      *d_src;	/* compressed image (or batch window) in HBM */

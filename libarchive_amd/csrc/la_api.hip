@@ -342,6 +342,7 @@ int la_gpu_lz4_decode(la_gpu_ctx *c, const la_lz4_batch *bt)
 	const bool fast = !(bt->options & LA_LZ4_OPT_GENERAL_ONLY);
 	const bool verify = !(bt->options & LA_LZ4_OPT_NO_VERIFY);
 	const bool queue = (bt->options & LA_LZ4_OPT_EXPAND_QUEUE) != 0;
+	const bool wide = (bt->options & LA_LZ4_OPT_EXPAND_WIDE) != 0;
 	lz4_ws w;
 	lz4_ws_layout(&w, NULL, bt->n_blocks, bt->src_bytes, fast);
 	if (w.total > c->ws_bytes) {
@@ -405,7 +406,7 @@ int la_gpu_lz4_decode(la_gpu_ctx *c, const la_lz4_batch *bt)
 	    fast ? 0xFFFFFFFEu : 0u,	/* the LDS-window kernel takes every eligible block that got a table ... */
 	    bt->hist_len, LA_LZ4_LONG_SEQ_BYTES);	/* ... except blocks of few long sequences (la_dev.h) */
 	prof_close(c, h, sx);
-	if (fast) {
+	if (fast && !wide) {
 		/* eligible blocks with more sequences than one LDS segment: classified on the device,
 		 * shared out over a small grid (a no-op launch when there are none) */
 		h = prof_open(c, "lz4_expand_big", sx);
@@ -418,7 +419,13 @@ int la_gpu_lz4_decode(la_gpu_ctx *c, const la_lz4_batch *bt)
 		HIPCHK(c, hipMemsetAsync(bt->d_frame_status, 0, (size_t)bt->n_frames * sizeof(uint32_t), sx));
 	for (uint32_t i = 0; i < nsl; i++) {
 		const uint32_t first = (uint32_t)((uint64_t)n * i / nsl), last = (uint32_t)((uint64_t)n * (i + 1) / nsl);
-		if (fast) {
+		if (fast && wide) {
+			h = prof_open(c, "lz4_expand", sx);
+			la_launch_lz4_expand_wide(sx, bt->d_src, bt->src_bytes, bt->d_blocks + first, last - first, bt->d_dst,
+			    bt->dst_cap, bt->d_dst_off + first, bt->d_out_len + first, bt->d_block_status + first,
+			    w.nseq + first, w.table, w.table_off + first, LA_LZ4_LONG_SEQ_BYTES);
+			prof_close(c, h, sx);
+		} else if (fast) {
 			h = prof_open(c, "lz4_expand", sx);
 			(queue ? la_launch_lz4_expand_queue : la_launch_lz4_expand_fast)(sx, bt->d_src, bt->src_bytes, bt->d_blocks + first, last - first, bt->d_dst,
 			    bt->dst_cap, bt->d_dst_off + first, bt->d_out_len + first, bt->d_block_status + first,
