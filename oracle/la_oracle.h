@@ -122,4 +122,10 @@ size_t orc_gzip_header_len(const uint8_t *p, size_t avail, uint32_t *mtime,
 #ifdef __cplusplus
 }
 #endif
+/* orc_zstd.c: Zstandard (RFC 8878) restated for the zstd read filter (libarchive/archive_read_support_filter_zstd.c) */
+uint64_t orc_xxh64(const void *input, size_t len, uint64_t seed);
+int orc_zstd_bid(const uint8_t *p, size_t avail);
+int orc_zstd_stream_decode(const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap, size_t *out_len,
+    char *msg, size_t msg_cap);
+
 #endif

@@ -34,7 +34,26 @@ FIXTURES = [
     ("cat/test/test_empty.gz.uu", "gzip", 0, hashlib.sha256(b"").hexdigest(), "cat/test/test_empty_gz.c"),
     ("tar/test/test_extract.tar.lz4.uu", "lz4", 3072, EXTRACT, "tar/test/test_extract_tar_lz4.c"),
     ("tar/test/test_extract.tar.gz.uu", "gzip", 3072, EXTRACT, "tar/test/test_extract_tar_gz.c"),
+    # zstd: the expected payload is what the image's libzstd (the library the reference's filter calls)
+    # produces for the same bytes -- size None = computed below with ZSTD_decompress
+    ("cat/test/test_expand.zst.uu", "zstd", None, None, "cat/test/test_expand_zstd.c:9-22 'contents of test_expand.zst.'"),
+    ("cat/test/test_empty.zst.uu", "zstd", None, None, "cat/test/test_empty_zstd.c:9-22"),
+    ("libarchive/test/test_compat_zstd_1.tar.zst.uu", "zstd", None, None, "test_compat_zstd.c:40-84: 3 frames with a skippable frame in the middle, 6 tar entries"),
+    ("libarchive/test/test_compat_zstd_2.tar.zst.uu", "zstd", None, None, "test_compat_zstd.c:84-86: the same sample from pzstd"),
 ]
+
+
+def libzstd_decompress(raw):
+    import ctypes
+    z = ctypes.CDLL("libzstd.so.1")
+    z.ZSTD_decompress.restype = ctypes.c_size_t
+    z.ZSTD_decompress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
+    z.ZSTD_isError.restype = ctypes.c_uint
+    z.ZSTD_isError.argtypes = [ctypes.c_size_t]
+    buf = ctypes.create_string_buffer(1 << 24)
+    n = z.ZSTD_decompress(buf, len(buf), raw, len(raw))
+    assert not z.ZSTD_isError(n)
+    return buf.raw[:n]
 
 
 # ZIP fixtures of the reference's zip reader tests: stored / deflate entries the GPU reader takes, plus
@@ -115,6 +134,9 @@ def main():
         raw = uudecode(open(os.path.join(REF, rel), "r", errors="replace").read())
         name = os.path.basename(rel)[:-3]
         open(os.path.join(OUT, name), "wb").write(raw)
+        if codec == "zstd" and size is None:
+            plain = libzstd_decompress(raw)
+            size, sha = len(plain), hashlib.sha256(plain).hexdigest()
         manifest.append({"file": name, "source": rel, "codec": codec, "decoded_size": size,
                          "decoded_sha256": sha, "pins": note, "stream_sha256": hashlib.sha256(raw).hexdigest()})
         print(name, len(raw))
