@@ -32,6 +32,7 @@ extern "C" {
 #define ARCHIVE_FILTER_NONE 0
 #define ARCHIVE_FILTER_GZIP 1
 #define ARCHIVE_FILTER_LZ4  13
+#define ARCHIVE_FILTER_ZSTD 14
 
 #define ARCHIVE_FORMAT_RAW   0x90000	/* archive.h */
 #define ARCHIVE_FORMAT_EMPTY 0x60000
@@ -53,6 +54,7 @@ int  archive_read_support_filter_all(struct archive *);				/* archive.h:457 */
 int  archive_read_support_filter_gzip(struct archive *);			/* archive.h:466 */
 int  archive_read_support_compression_gzip(struct archive *);			/* deprecated alias, gzip.c:85-92 */
 int  archive_read_support_filter_lz4(struct archive *);				/* archive.h:469 */
+int  archive_read_support_filter_zstd(struct archive *);			/* archive.h:482 */
 int  archive_read_support_filter_none(struct archive *);
 int  archive_read_support_format_raw(struct archive *);
 int  archive_read_support_format_empty(struct archive *);

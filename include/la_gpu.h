@@ -90,7 +90,15 @@ enum {
 	LA_ST_GZ_BAD_CRC          = 7,	/* NEW (reference never checks, gzip.c:423) */
 	LA_ST_GZ_BAD_ISIZE        = 8,	/* NEW */
 	LA_ST_GZ_OUT_FULL         = 9,	/* member produced more than dst_cap bytes: host retries with a larger slot */
-	LA_ST_GZ_NO_TRAILER       = 10	/* deflate body complete, fewer than 8 trailer bytes inside src_len (gzip.c:419-421) */
+	LA_ST_GZ_NO_TRAILER       = 10,	/* deflate body complete, fewer than 8 trailer bytes inside src_len (gzip.c:419-421) */
+	/* zstd.c:226-231 -> "Zstd decompression failed: <libzstd's name of the error>" */
+	LA_ST_ZSTD_CORRUPT        = 11,	/* "Corrupted block detected" */
+	LA_ST_ZSTD_TRUNCATED      = 12,	/* the frame needs more bytes than src_len (zstd.c:213-217 "Truncated zstd input") */
+	LA_ST_ZSTD_BAD_CHECKSUM   = 13,	/* "Restored data doesn't match checksum" */
+	LA_ST_ZSTD_OUT_FULL       = 14,	/* the frame produces more than dst_cap bytes: host retries with a larger slot */
+	LA_ST_ZSTD_UNSUPPORTED    = 15,	/* reserved header bit: "Unsupported frame parameter" */
+	LA_ST_ZSTD_WINDOW         = 16,	/* window above 2^27 (ZSTD_decompressStream's default limit): "Frame requires too much memory for decoding" */
+	LA_ST_ZSTD_DICTIONARY     = 17	/* the frame names a dictionary: "Dictionary mismatch" */
 };
 
 /* =====================================================================
@@ -249,6 +257,42 @@ typedef struct la_gz_batch {
 					 * the CRC32 of the produced bytes are reported */
 
 int la_gpu_gzip_decode(la_gpu_ctx *ctx, const la_gz_batch *batch);
+
+/* =====================================================================
+ * Zstandard -- replaces, for a batch of whole frames per call, the ZSTD_decompressStream loop of
+ * zstd_filter_read (libarchive/archive_read_support_filter_zstd.c:171-260; libzstd is the reference's
+ * external dependency for this codec): frame header, raw / RLE / compressed blocks, XXH64 content checksum.
+ * The host walks the frame and block headers (la_zstd_index_build, include/la_host.h), drops skippable
+ * frames and fills this table; one frame = one unit (a frame is one serial chain).
+ * ===================================================================== */
+typedef struct la_zstd_frame {
+	uint64_t src_off;	/* the frame's magic number inside d_src */
+	uint64_t src_len;	/* bytes of the whole frame (header .. last block / checksum) */
+	uint64_t dst_off;	/* where its output goes inside d_dst */
+	uint64_t dst_cap;	/* capacity reserved for it: Frame_Content_Size when the header carries one, else the walker's bound */
+} la_zstd_frame;
+
+typedef struct la_zstd_result {
+	uint32_t status;	/* LA_ST_* */
+	uint32_t reserved;
+	uint64_t out_len;	/* bytes produced (0 on error) */
+} la_zstd_result;
+
+typedef struct la_zstd_batch {
+	const uint8_t       *d_src;
+	uint64_t             src_bytes;
+	const la_zstd_frame *d_frames;
+	uint32_t             n_frames;
+	uint32_t             options;	/* LA_ZSTD_OPT_* */
+	uint8_t             *d_dst;
+	uint64_t             dst_cap;
+	la_zstd_result      *d_results;	/* [n_frames] */
+} la_zstd_batch;
+
+#define LA_ZSTD_OPT_NO_VERIFY 1u	/* skip the content checksum */
+
+uint64_t la_gpu_zstd_workspace_bytes(uint32_t n_frames);
+int      la_gpu_zstd_decode(la_gpu_ctx *ctx, const la_zstd_batch *batch);
 
 /* =====================================================================
  * LZ4 compression -- the data plane of the lz4 WRITE filter: replaces, for a whole

@@ -32,9 +32,12 @@ enum {
 	LA_END_EMPTY_FRAME,	/* a frame without blocks: its checksum is verified, then the stream ends (SURVEY F11 i) */
 	LA_END_NEED_MORE,	/* window ended inside an item and more input may follow (at_eof == 0) */
 	LA_END_GZ_NO_TRAILER,	/* deflate body complete, trailer short: ARCHIVE_FATAL without message (gzip.c:419-421) */
-	LA_END_GZ_TOO_LARGE	/* a gzip member of 4 GiB or more (compressed span or decoded size): beyond the 32-bit member
+	LA_END_GZ_TOO_LARGE,	/* a gzip member of 4 GiB or more (compressed span or decoded size): beyond the 32-bit member
 				 * table of this data plane -- an explicit error, never a wrong byte (the reference streams such
 				 * members; a deployment keeps the reference filter for them) */
+	LA_END_ZSTD_BAD_MAGIC,	/* bytes that are neither a zstd nor a skippable frame where a frame must start: libzstd's
+				 * "Unknown frame descriptor" (zstd.c:226-231) */
+	LA_END_ZSTD_BAD_BLOCK	/* the last indexed frame stops at a reserved block type / oversized block: the device names it */
 };
 
 typedef struct la_lz4_index {
@@ -113,6 +116,20 @@ int    la_gz_index_build3(const uint8_t *img, uint64_t len, int at_eof, uint32_t
 int    la_gz_index_build4(const uint8_t *img, uint64_t len, int at_eof, uint32_t first_skip,
            uint32_t first_cap, uint32_t flags, uint64_t out_budget, la_gz_index *idx);
 void   la_gz_index_free(la_gz_index *idx);
+
+/* ---- zstd (host/la_zstd_index.c) ---- */
+typedef struct la_zstd_index_result {
+	uint32_t n_frames;	/* entries written to frames[] (skippable frames are passed over) */
+	int      end_kind;	/* LA_END_EOF, _TRUNCATED, _NEED_MORE, _ZSTD_BAD_MAGIC, _ZSTD_BAD_BLOCK */
+	uint64_t consumed;	/* bytes of the image covered by the indexed frames (and the skippable ones between them) */
+	uint64_t dst_bytes;	/* decoded bytes the slots ask for (16-byte aligned slots back to back) */
+	int      window_full;	/* stopped because of cap / out_budget, not because of the input */
+} la_zstd_index_result;
+/* zstd.c:107-131 over a peeked buffer */
+int la_zstd_bid_bytes(const uint8_t *p, size_t avail);
+/* Frame table of img[0..len): frame and block headers only.  out_budget as for the other walkers. */
+int la_zstd_index_build(const uint8_t *img, uint64_t len, int at_eof, uint64_t out_budget, la_zstd_frame *frames,
+        uint32_t cap, la_zstd_index_result *res);
 
 /* ---- hash drop-ins (host/la_hash_dropin.c) ----
  * The 4-pointer table of libarchive/archive_xxhash.h:37-46 (defined as `__archive_xxhash` when built

@@ -460,6 +460,31 @@ int la_gpu_lz4_decode(la_gpu_ctx *c, const la_lz4_batch *bt)
 	return LA_OK;
 }
 
+uint64_t la_gpu_zstd_workspace_bytes(uint32_t n_frames)
+{
+	return la_zstd_workspace_bytes(n_frames);
+}
+
+int la_gpu_zstd_decode(la_gpu_ctx *c, const la_zstd_batch *bt)
+{
+	if (!c || !bt)
+		return LA_ERR_ARG;
+	if (bt->n_frames && (!bt->d_src || !bt->d_frames || !bt->d_dst || !bt->d_results))
+		return LA_ERR_ARG;
+	const uint64_t need = la_zstd_workspace_bytes(bt->n_frames);
+	if (need > c->ws_bytes) {
+		int rc = la_gpu_reserve(c, need);
+		if (rc != LA_OK) return rc;
+	}
+	prof_begin(c);
+	int h = prof_open(c, "zstd_frames", c->stream);
+	la_launch_zstd_frames(c->stream, bt->d_src, bt->src_bytes, bt->d_frames, bt->n_frames, bt->d_dst, bt->dst_cap,
+	    bt->d_results, (uint8_t *)c->ws, bt->options);
+	prof_close(c, h, c->stream);
+	HIPCHK(c, hipGetLastError());
+	return LA_OK;
+}
+
 int la_gpu_gzip_decode(la_gpu_ctx *c, const la_gz_batch *bt)
 {
 	if (!c || !bt)

@@ -1,0 +1,532 @@
+/*
+ * la_zstd.hip -- Zstandard frame decoder for gfx950, first cut: the data plane of the zstd read filter
+ * (SURVEY section 8 f3).  Replaces, for a batch of whole frames per call, what the reference's filter gets from
+ * libzstd's ZSTD_decompressStream (libarchive/archive_read_support_filter_zstd.c:171-260): frame header, raw / RLE /
+ * compressed blocks (Huffman literals in 1 or 4 streams with direct or FSE-coded weights, FSE sequences with
+ * predefined / RLE / described / repeated tables, repeat offsets), and the XXH64 content checksum (RFC 8878).
+ *
+ * Parallelism is ACROSS frames only: one lane decodes one frame from its first byte to its checksum (a frame is one
+ * serial chain: every block may reach back into the previous ones, entropy tables and repeat offsets carry over).
+ * Tables and the literals buffer of a lane live in a workspace slot in HBM (144 KiB per lane).  That is the shape of
+ * pzstd output and of seekable / chunked .zst files (many frames); a one-frame .zst runs on ONE lane and is this
+ * design's worst case, like a one-member .gz (DESIGN.md known limits).  No attempt at speed yet: byte-wise bit
+ * reader, byte-wise match copies.
+ */
+#include "la_dev.h"
+
+#define P64_1 11400714785074694791ULL
+#define P64_2 14029467366897019727ULL
+#define P64_3 1609587929392839161ULL
+#define P64_4 9650029242287828579ULL
+#define P64_5 2870177450012600261ULL
+__device__ static uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+__device__ static uint64_t rd64(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+__device__ static uint32_t rd32(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+__device__ static uint64_t xxh64_round(uint64_t acc, uint64_t in) { acc += in * P64_2; acc = rotl64(acc, 31); return acc * P64_1; }
+__device__ static uint64_t xxh64_merge(uint64_t h, uint64_t v) { v = xxh64_round(0, v); h ^= v; return h * P64_1 + P64_4; }
+
+/* XXH64 (the frame's content checksum is its low 32 bits, RFC 8878 3.1.1) */
+__device__ static uint64_t dev_xxh64(const uint8_t *p, size_t len, uint64_t seed)
+{
+	const uint8_t *end = p + len;
+	uint64_t h;
+	if (len >= 32) {
+		uint64_t v1 = seed + P64_1 + P64_2, v2 = seed + P64_2, v3 = seed, v4 = seed - P64_1;
+		do {
+			v1 = xxh64_round(v1, rd64(p)); v2 = xxh64_round(v2, rd64(p + 8));
+			v3 = xxh64_round(v3, rd64(p + 16)); v4 = xxh64_round(v4, rd64(p + 24));
+			p += 32;
+		} while (p + 32 <= end);
+		h = rotl64(v1, 1) + rotl64(v2, 7) + rotl64(v3, 12) + rotl64(v4, 18);
+		h = xxh64_merge(h, v1); h = xxh64_merge(h, v2); h = xxh64_merge(h, v3); h = xxh64_merge(h, v4);
+	} else {
+		h = seed + P64_5;
+	}
+	h += (uint64_t)len;
+	while (p + 8 <= end) { h ^= xxh64_round(0, rd64(p)); h = rotl64(h, 27) * P64_1 + P64_4; p += 8; }
+	if (p + 4 <= end) { h ^= (uint64_t)rd32(p) * P64_1; h = rotl64(h, 23) * P64_2 + P64_3; p += 4; }
+	while (p < end) { h ^= (uint64_t)(*p++) * P64_5; h = rotl64(h, 11) * P64_1; }
+	h ^= h >> 33; h *= P64_2; h ^= h >> 29; h *= P64_3; h ^= h >> 32;
+	return h;
+}
+
+__device__ static void dev_copy(uint8_t *d, const uint8_t *s, size_t n)
+{
+	size_t i = 0;
+	for (; i + 8 <= n; i += 8) { uint64_t v; __builtin_memcpy(&v, s + i, 8); __builtin_memcpy(d + i, &v, 8); }
+	for (; i < n; i++) d[i] = s[i];
+}
+__device__ static void dev_fill(uint8_t *d, uint8_t v, size_t n)
+{
+	const uint64_t w = 0x0101010101010101ull * v;
+	size_t i = 0;
+	for (; i + 8 <= n; i += 8) __builtin_memcpy(d + i, &w, 8);
+	for (; i < n; i++) d[i] = v;
+}
+
+/* ---- bit readers ---- */
+/* n (<= 32) bits at bit position pos of the little-endian bit array src[0..len); positions outside read as zero */
+__device__ static uint32_t bits_at(const uint8_t *src, size_t len, int64_t pos, unsigned n)
+{
+	uint64_t v = 0;
+	if (n == 0) return 0;
+	for (int i = 0; i < 6; i++) {	/* up to 6 bytes cover 32 bits at any bit phase */
+		int64_t byte = (pos >> 3) + i;	/* arithmetic shift: floor for negative positions */
+		uint64_t b = (byte >= 0 && (uint64_t)byte < len) ? src[byte] : 0;
+		v |= b << (8 * i);
+	}
+	v >>= (unsigned)(pos & 7);
+	return (uint32_t)(v & ((n >= 32) ? 0xFFFFFFFFull : ((1ull << n) - 1)));
+}
+__device__ static int highbit(uint32_t v) { int r = -1; while (v) { v >>= 1; r++; } return r; }
+
+/* backward stream: returns the bit position just below the end marker, or -1 when the last byte is zero */
+__device__ static int64_t rev_init(const uint8_t *src, size_t len)
+{
+	if (len == 0 || src[len - 1] == 0) return -1;
+	return (int64_t)(len - 1) * 8 + highbit(src[len - 1]);
+}
+__device__ static uint32_t rev_read(const uint8_t *src, size_t len, int64_t *pos, unsigned n)
+{
+	*pos -= n;
+	return bits_at(src, len, *pos, n);
+}
+
+/* ---- FSE ---- */
+typedef struct { uint8_t sym, nbits; uint16_t base; } fse_ent;
+typedef struct { fse_ent e[512]; int al; } fse_tab;
+
+/* normalized counts (RFC 8878 4.1.1); returns bytes consumed or -1 */
+__device__ static int fse_read_ncount(const uint8_t *src, size_t len, int max_al, int max_sym, int16_t *norm, int *n_sym, int *al_out)
+{
+	int64_t bp = 0;
+	if (len == 0) return -1;
+	const int al = (int)bits_at(src, len, bp, 4) + 5; bp += 4;
+	if (al > max_al) return -1;
+	int remaining = (1 << al) + 1, threshold = 1 << al, nbits = al + 1, sym = 0;
+	while (remaining > 1 && sym <= max_sym) {
+		if ((size_t)((bp + 7) >> 3) > len + 4) return -1;
+		const int max = (2 * threshold - 1) - remaining;
+		int count;
+		const uint32_t v = bits_at(src, len, bp, (unsigned)nbits);
+		if ((int)(v & (uint32_t)(threshold - 1)) < max) {
+			count = (int)(v & (uint32_t)(threshold - 1));
+			bp += nbits - 1;
+		} else {
+			count = (int)(v & (uint32_t)(2 * threshold - 1));
+			if (count >= threshold) count -= max;
+			bp += nbits;
+		}
+		count--;	/* -1 = "less than one" */
+		remaining -= count < 0 ? -count : count;
+		norm[sym++] = (int16_t)count;
+		if (count == 0) {	/* repeat flags: runs of zero probabilities */
+			for (;;) {
+				const uint32_t r = bits_at(src, len, bp, 2); bp += 2;
+				for (uint32_t i = 0; i < r; i++) { if (sym > max_sym) return -1; norm[sym++] = 0; }
+				if (r != 3) break;
+			}
+		}
+		if (remaining < 1) return -1;
+		while (remaining < threshold) { nbits--; threshold >>= 1; }
+	}
+	if (remaining != 1 || sym > max_sym + 1) return -1;
+	const size_t used = (size_t)((bp + 7) >> 3);
+	if (used > len) return -1;
+	*n_sym = sym; *al_out = al;
+	return (int)used;
+}
+
+__device__ static int fse_build(fse_tab *t, const int16_t *norm, int n_sym, int al)
+{
+	const int size = 1 << al;
+	uint16_t next[256];
+	int high = size - 1;
+	t->al = al;
+	for (int s = 0; s < n_sym; s++) {
+		if (norm[s] == -1) { t->e[high--].sym = (uint8_t)s; next[s] = 1; }
+		else next[s] = (uint16_t)norm[s];
+	}
+	const int step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
+	int pos = 0;
+	for (int s = 0; s < n_sym; s++)
+		for (int i = 0; i < norm[s]; i++) {
+			t->e[pos].sym = (uint8_t)s;
+			do { pos = (pos + step) & mask; } while (pos > high);
+		}
+	if (pos != 0) return -1;
+	for (int u = 0; u < size; u++) {
+		const int s = t->e[u].sym;
+		const int nx = next[s]++;
+		const int nb = al - highbit((uint32_t)nx);
+		t->e[u].nbits = (uint8_t)nb;
+		t->e[u].base = (uint16_t)((nx << nb) - size);
+	}
+	return 0;
+}
+__device__ static void fse_rle(fse_tab *t, int sym) { t->al = 0; t->e[0].sym = (uint8_t)sym; t->e[0].nbits = 0; t->e[0].base = 0; }
+
+/* ---- Huffman (RFC 8878 4.2) ---- */
+typedef struct { uint8_t sym[2048], nbits[2048]; int maxbits; } huf_tab;
+
+__device__ static int huf_read(huf_tab *h, const uint8_t *src, size_t len)	/* returns bytes consumed or -1 */
+{
+	uint8_t w[256];
+	int n = 0;
+	size_t used;
+	if (len < 1) return -1;
+	const int hb = src[0];
+	if (hb >= 128) {	/* direct: 4-bit weights */
+		n = hb - 127;
+		used = 1 + (size_t)(n + 1) / 2;
+		if (used > len) return -1;
+		for (int i = 0; i < n; i++)
+			w[i] = (i & 1) ? (src[1 + i / 2] & 15) : (src[1 + i / 2] >> 4);
+	} else {		/* FSE-compressed weights, two interleaved states */
+		used = 1 + (size_t)hb;
+		if (hb == 0 || used > len) return -1;
+		int16_t norm[16]; int ns, al;
+		fse_tab t;
+		const int c = fse_read_ncount(src + 1, (size_t)hb, 6, 11, norm, &ns, &al);
+		if (c < 0 || fse_build(&t, norm, ns, al) < 0) return -1;
+		const uint8_t *bs = src + 1 + c; const size_t bl = (size_t)hb - (size_t)c;
+		int64_t pos = rev_init(bs, bl);
+		if (pos < 0) return -1;
+		uint32_t s1 = rev_read(bs, bl, &pos, (unsigned)al), s2 = rev_read(bs, bl, &pos, (unsigned)al);
+		if (pos < 0) return -1;
+		for (;;) {
+			if (n > 253) return -1;
+			w[n++] = t.e[s1].sym;
+			s1 = t.e[s1].base + rev_read(bs, bl, &pos, t.e[s1].nbits);
+			if (pos < 0) { w[n++] = t.e[s2].sym; break; }
+			if (n > 253) return -1;
+			w[n++] = t.e[s2].sym;
+			s2 = t.e[s2].base + rev_read(bs, bl, &pos, t.e[s2].nbits);
+			if (pos < 0) { w[n++] = t.e[s1].sym; break; }
+		}
+	}
+	/* the last weight completes a power of two */
+	uint32_t sum = 0;
+	for (int i = 0; i < n; i++) { if (w[i] > 11) return -1; if (w[i]) sum += 1u << (w[i] - 1); }
+	if (sum == 0) return -1;
+	const int maxbits = highbit(sum) + 1;
+	if (maxbits > 11) return -1;
+	const uint32_t left = (1u << maxbits) - sum;
+	if (left == 0 || (left & (left - 1))) return -1;
+	w[n++] = (uint8_t)(highbit(left) + 1);
+	h->maxbits = maxbits;
+	uint32_t pos = 0;
+	for (int wt = 1; wt <= maxbits; wt++)
+		for (int s = 0; s < n; s++)
+			if (w[s] == wt) {
+				const uint32_t cnt = 1u << (wt - 1);
+				for (uint32_t i = 0; i < cnt; i++) { h->sym[pos + i] = (uint8_t)s; h->nbits[pos + i] = (uint8_t)(maxbits + 1 - wt); }
+				pos += cnt;
+			}
+	if (pos != (1u << maxbits)) return -1;
+	return (int)used;
+}
+
+__device__ static int huf_stream(const huf_tab *h, const uint8_t *src, size_t len, uint8_t *out, size_t n)
+{
+	int64_t pos = rev_init(src, len);
+	if (pos < 0) return -1;
+	for (size_t i = 0; i < n; i++) {
+		const uint32_t idx = bits_at(src, len, pos - h->maxbits, (unsigned)h->maxbits);
+		out[i] = h->sym[idx];
+		pos -= h->nbits[idx];
+		if (pos < 0) return -1;
+	}
+	return pos == 0 ? 0 : -1;
+}
+
+/* ---- sequences ---- */
+__device__ static const uint32_t LL_BASE[36] = { 0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,18,20,22,24,28,32,40,48,64,128,256,512,1024,2048,4096,8192,16384,32768,65536 };
+__device__ static const uint8_t LL_BITS[36] = { 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,2,2,3,3,4,6,7,8,9,10,11,12,13,14,15,16 };
+__device__ static const uint32_t ML_BASE[53] = { 3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,32,33,34,35,37,39,41,43,47,51,59,67,83,99,131,259,515,1027,2051,4099,8195,16387,32771,65539 };
+__device__ static const uint8_t ML_BITS[53] = { 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,2,2,3,3,4,4,5,7,8,9,10,11,12,13,14,15,16 };
+__device__ static const int16_t LL_DEF[36] = { 4,3,2,2,2,2,2,2,2,2,2,2,2,1,1,1,2,2,2,2,2,2,2,2,2,3,2,1,1,1,1,1,-1,-1,-1,-1 };
+__device__ static const int16_t ML_DEF[53] = { 1,4,3,2,2,2,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1,-1,-1 };
+__device__ static const int16_t OF_DEF[29] = { 1,1,1,1,1,1,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1 };
+
+typedef struct {
+	huf_tab huf; int have_huf;
+	fse_tab ll, of, ml; int have_ll, have_of, have_ml;
+	uint32_t rep[3];
+	uint8_t *lit;	/* 128 KiB + slack */
+} zframe;
+
+/* one table of the sequences section; returns bytes consumed or -1 */
+__device__ static int seq_table(fse_tab *t, int *have, int mode, const uint8_t *src, size_t len, int max_al, int max_sym,
+    const int16_t *def, int def_n, int def_al)
+{
+	if (mode == 0) { if (fse_build(t, def, def_n, def_al) < 0) return -1; *have = 1; return 0; }
+	if (mode == 1) { if (len < 1 || src[0] > max_sym) return -1; fse_rle(t, src[0]); *have = 1; return 1; }
+	if (mode == 2) {
+		int16_t norm[64]; int ns, al;
+		const int c = fse_read_ncount(src, len, max_al, max_sym, norm, &ns, &al);
+		if (c < 0 || fse_build(t, norm, ns, al) < 0) return -1;
+		*have = 1;
+		return c;
+	}
+	return *have ? 0 : -1;	/* repeat */
+}
+
+#define ZBLOCK_MAX (128u * 1024u)
+
+/* one compressed block; returns bytes produced or -1 */
+__device__ static int64_t zstd_block(zframe *f, const uint8_t *src, size_t len, uint8_t *dst, size_t dst_pos, size_t dst_cap)
+{
+	if (len < 1) return -1;	/* (libzstd: a compressed block needs at least a literals header) */
+	/* ---- literals section ---- */
+	const int ltype = src[0] & 3, sf = (src[0] >> 2) & 3;
+	size_t hl, regen, comp = 0;
+	int streams = 1;
+	if (ltype < 2) {
+		if (sf == 0 || sf == 2) { hl = 1; regen = src[0] >> 3; }
+		else if (sf == 1) { if (len < 2) return -1; hl = 2; regen = (src[0] >> 4) | ((size_t)src[1] << 4); }
+		else { if (len < 3) return -1; hl = 3; regen = (src[0] >> 4) | ((size_t)src[1] << 4) | ((size_t)src[2] << 12); }
+	} else {
+		if (sf < 2) {
+			if (len < 3) return -1;
+			hl = 3; streams = sf == 0 ? 1 : 4;
+			const uint32_t v = src[0] | ((uint32_t)src[1] << 8) | ((uint32_t)src[2] << 16);
+			regen = (v >> 4) & 0x3FF; comp = (v >> 14) & 0x3FF;
+		} else if (sf == 2) {
+			if (len < 4) return -1;
+			hl = 4; streams = 4;
+			const uint32_t v = rd32(src);
+			regen = (v >> 4) & 0x3FFF; comp = v >> 18;
+		} else {
+			if (len < 5) return -1;
+			hl = 5; streams = 4;
+			const uint64_t v = (uint64_t)rd32(src) | ((uint64_t)src[4] << 32);
+			regen = (size_t)((v >> 4) & 0x3FFFF); comp = (size_t)(v >> 22);
+		}
+	}
+	if (regen > ZBLOCK_MAX) return -1;
+	const uint8_t *p = src + hl;
+	size_t left = len - hl;
+	if (ltype == 0) { if (regen > left) return -1; dev_copy(f->lit, p, regen); p += regen; left -= regen; }
+	else if (ltype == 1) { if (left < 1) return -1; dev_fill(f->lit, p[0], regen); p += 1; left -= 1; }
+	else {
+		if (comp > left) return -1;
+		const uint8_t *hp = p; size_t hleft = comp;
+		if (ltype == 2) {
+			const int c = huf_read(&f->huf, hp, hleft);
+			if (c < 0) return -1;
+			f->have_huf = 1; hp += c; hleft -= (size_t)c;
+		} else if (!f->have_huf) return -1;
+		if (streams == 1) {
+			if (huf_stream(&f->huf, hp, hleft, f->lit, regen) < 0) return -1;
+		} else {
+			if (hleft < 6) return -1;
+			const size_t s1 = hp[0] | ((size_t)hp[1] << 8), s2 = hp[2] | ((size_t)hp[3] << 8), s3 = hp[4] | ((size_t)hp[5] << 8);
+			if (6 + s1 + s2 + s3 > hleft) return -1;
+			const size_t s4 = hleft - 6 - s1 - s2 - s3, q = (regen + 3) / 4;
+			if (3 * q > regen) return -1;
+			hp += 6;
+			if (huf_stream(&f->huf, hp, s1, f->lit, q) < 0) return -1;
+			if (huf_stream(&f->huf, hp + s1, s2, f->lit + q, q) < 0) return -1;
+			if (huf_stream(&f->huf, hp + s1 + s2, s3, f->lit + 2 * q, q) < 0) return -1;
+			if (huf_stream(&f->huf, hp + s1 + s2 + s3, s4, f->lit + 3 * q, regen - 3 * q) < 0) return -1;
+		}
+		p += comp; left -= comp;
+	}
+	/* ---- sequences section ---- */
+	if (left < 1) return -1;
+	size_t nseq = p[0];
+	if (nseq == 0) { p += 1; left -= 1; }
+	else if (nseq < 128) { p += 1; left -= 1; }
+	else if (nseq < 255) { if (left < 2) return -1; nseq = ((nseq - 128) << 8) + p[1]; p += 2; left -= 2; }
+	else { if (left < 3) return -1; nseq = p[1] + ((size_t)p[2] << 8) + 0x7F00; p += 3; left -= 3; }
+	size_t out = dst_pos, lit_pos = 0;
+	if (nseq) {
+		if (left < 1) return -1;
+		const int modes = p[0];
+		/* (bits 0-1 are reserved; libzstd 1.4.8 ZSTD_decodeSeqHeaders does not look at them) */
+		p += 1; left -= 1;
+		int c;
+		c = seq_table(&f->ll, &f->have_ll, modes >> 6, p, left, 9, 35, LL_DEF, 36, 6); if (c < 0) return -1; p += c; left -= (size_t)c;
+		c = seq_table(&f->of, &f->have_of, (modes >> 4) & 3, p, left, 8, 31, OF_DEF, 29, 5); if (c < 0) return -1; p += c; left -= (size_t)c;
+		c = seq_table(&f->ml, &f->have_ml, (modes >> 2) & 3, p, left, 9, 52, ML_DEF, 53, 6); if (c < 0) return -1; p += c; left -= (size_t)c;
+		int64_t pos = rev_init(p, left);
+		if (pos < 0) return -1;
+		uint32_t sl = rev_read(p, left, &pos, (unsigned)f->ll.al);
+		uint32_t so = rev_read(p, left, &pos, (unsigned)f->of.al);
+		uint32_t sm = rev_read(p, left, &pos, (unsigned)f->ml.al);
+		if (pos < 0) return -1;
+		for (size_t i = 0; i < nseq; i++) {
+			const int oc = f->of.e[so].sym, mc = f->ml.e[sm].sym, lc = f->ll.e[sl].sym;
+			if (oc > 31 || mc > 52 || lc > 35) return -1;
+			const uint32_t ov = (oc ? ((1u << oc) + rev_read(p, left, &pos, (unsigned)oc)) : 1u);
+			const uint32_t ml = ML_BASE[mc] + rev_read(p, left, &pos, ML_BITS[mc]);
+			const uint32_t ll = LL_BASE[lc] + rev_read(p, left, &pos, LL_BITS[lc]);
+			if (pos < 0) return -1;
+			uint32_t offset;
+			if (ov > 3) {
+				offset = ov - 3;
+				f->rep[2] = f->rep[1]; f->rep[1] = f->rep[0]; f->rep[0] = offset;
+			} else {
+				uint32_t idx = ov - 1 + (ll == 0 ? 1u : 0u);	/* 0..3 */
+				if (idx == 0) offset = f->rep[0];
+				else {
+					offset = idx == 3 ? f->rep[0] - 1 : f->rep[idx];
+					if (offset == 0) return -1;
+					if (idx != 1) f->rep[2] = f->rep[1];
+					f->rep[1] = f->rep[0]; f->rep[0] = offset;
+				}
+			}
+			if (i + 1 < nseq) {
+				sl = f->ll.e[sl].base + rev_read(p, left, &pos, f->ll.e[sl].nbits);
+				sm = f->ml.e[sm].base + rev_read(p, left, &pos, f->ml.e[sm].nbits);
+				so = f->of.e[so].base + rev_read(p, left, &pos, f->of.e[so].nbits);
+				if (pos < 0) return -1;
+			}
+			/* execute */
+			if (ll > regen - lit_pos) return -1;
+			if (out - dst_pos + ll + ml > ZBLOCK_MAX) return -1;
+			if (out + ll + ml > dst_cap) return -2;
+			dev_copy(dst + out, f->lit + lit_pos, ll); out += ll; lit_pos += ll;
+			if (offset > out) return -1;
+			for (uint32_t k = 0; k < ml; k++) dst[out + k] = dst[out + k - offset];
+			out += ml;
+		}
+		if (pos != 0) return -1;	/* (libzstd 1.5 checks the exact end too; 1.4.8 does not) */
+	} else if (left != 0) return -1;
+	const size_t rest = regen - lit_pos;
+	if (out - dst_pos + rest > ZBLOCK_MAX) return -1;
+	if (out + rest > dst_cap) return -2;
+	dev_copy(dst + out, f->lit + lit_pos, rest); out += rest;
+	return (int64_t)(out - dst_pos);
+}
+
+/* One frame at src (zstd or skippable).  *consumed = its compressed length.  Returns decoded bytes appended at
+ * dst + dst_pos, or -1 format error, -2 dst too small, -3 truncated input. */
+__device__ static int64_t zstd_frame(const uint8_t *src, size_t len, uint8_t *dst, size_t dst_pos, size_t dst_cap, size_t *consumed, zframe *fp, uint8_t *litbuf, uint32_t options)
+{
+	if (len < 4) return -3;
+	const uint32_t magic = rd32(src);
+	if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) {
+		if (len < 8) return -3;
+		const uint64_t sz = rd32(src + 4);
+		if (8 + sz > len) return -3;
+		*consumed = (size_t)(8 + sz);
+		return 0;
+	}
+	if (magic != 0xFD2FB528u) return -1;
+	if (len < 5) return -3;
+	const int fhd = src[4];
+	const int fcs_flag = fhd >> 6, single = (fhd >> 5) & 1, csum = (fhd >> 2) & 1, did_flag = fhd & 3;
+	if (fhd & 0x08) return -5;	/* reserved bit: "Unsupported frame parameter" */
+	size_t p = 5;
+	uint64_t window = 0;
+	if (!single) {
+		if (p >= len) return -3;
+		const int wd = src[p++];
+		const uint64_t base = 1ull << (10 + (wd >> 3));
+		window = base + (base >> 3) * (uint64_t)(wd & 7);
+	}
+	const int did_len[4] = { 0, 1, 2, 4 };
+	if (p + (size_t)did_len[did_flag] > len) return -3;
+	uint32_t did = 0;
+	for (int i = 0; i < did_len[did_flag]; i++) did |= (uint32_t)src[p + i] << (8 * i);
+	p += (size_t)did_len[did_flag];
+	const int fcs_len = fcs_flag == 0 ? single : (fcs_flag == 1 ? 2 : (fcs_flag == 2 ? 4 : 8));
+	if (p + (size_t)fcs_len > len) return -3;
+	uint64_t fcs = 0;
+	for (int i = 0; i < fcs_len; i++) fcs |= (uint64_t)src[p + i] << (8 * i);
+	if (fcs_len == 2) fcs += 256;
+	p += (size_t)fcs_len;
+	if (single) window = fcs;
+	if (did != 0) return -7;			/* no dictionary is ever loaded by the filter: "Dictionary mismatch" */
+	if (window > (1ull << 27)) return -6;	/* ZSTD_decompressStream's default window limit (2^27) */
+	zframe &f = *fp;
+	f.have_huf = f.have_ll = f.have_of = f.have_ml = 0;
+	f.rep[0] = 1; f.rep[1] = 4; f.rep[2] = 8;
+	f.lit = litbuf;
+	size_t out = dst_pos;
+	for (;;) {
+		if (p + 3 > len) return -3;
+		const uint32_t bh = src[p] | ((uint32_t)src[p + 1] << 8) | ((uint32_t)src[p + 2] << 16);
+		p += 3;
+		const int last = bh & 1, type = (bh >> 1) & 3;
+		const uint32_t bsize = bh >> 3;
+		if (type == 3) return -1;
+		if (bsize > ZBLOCK_MAX) return -1;
+		if (type == 1) {
+			if (p + 1 > len) return -3;
+			if (out + bsize > dst_cap) return -2;
+			dev_fill(dst + out, src[p], bsize); out += bsize; p += 1;
+		} else {
+			if (p + bsize > len) return -3;
+			if (type == 0) {
+				if (out + bsize > dst_cap) return -2;
+				dev_copy(dst + out, src + p, bsize); out += bsize;
+			} else {
+				const int64_t r = zstd_block(&f, src + p, bsize, dst + dst_pos, out - dst_pos, dst_cap - dst_pos);
+				if (r < 0) return r;
+				out += (size_t)r;
+			}
+			p += bsize;
+		}
+		if (last) break;
+	}
+	if (fcs_len && (uint64_t)(out - dst_pos) != fcs) return -1;
+	if (csum) {
+		if (p + 4 > len) return -3;
+		if (!(options & LA_ZSTD_OPT_NO_VERIFY) && (uint32_t)dev_xxh64(dst + dst_pos, out - dst_pos, 0) != rd32(src + p)) return -4;
+		p += 4;
+	}
+	*consumed = p;
+	return (int64_t)(out - dst_pos);
+}
+
+
+#define ZSTD_WS_STRIDE (144u * 1024u)	/* per lane: zframe (tables) + the literals buffer of one block */
+#define ZSTD_MAX_LANES 8192u
+
+__global__ __launch_bounds__(64) void zstd_frames_kernel(const uint8_t *__restrict__ src, uint64_t src_bytes,
+    const la_zstd_frame *__restrict__ frames, uint32_t n, uint8_t *dst, uint64_t dst_cap, la_zstd_result *results,
+    uint8_t *ws, uint32_t lanes, uint32_t options)
+{
+	const uint32_t w = blockIdx.x * 64u + threadIdx.x;
+	if (w >= lanes)
+		return;
+	zframe *fp = (zframe *)(ws + (size_t)w * ZSTD_WS_STRIDE);
+	uint8_t *lit = (uint8_t *)fp + 12288;
+	for (uint32_t i = w; i < n; i += lanes) {
+		const la_zstd_frame fr = frames[i];
+		la_zstd_result r;
+		r.status = LA_ST_ZSTD_CORRUPT; r.reserved = 0; r.out_len = 0;
+		if (fr.src_off <= src_bytes && fr.src_len <= src_bytes - fr.src_off && fr.dst_off <= dst_cap && fr.dst_cap <= dst_cap - fr.dst_off) {
+			size_t used = 0;
+			const int64_t v = zstd_frame(src + fr.src_off, (size_t)fr.src_len, dst + fr.dst_off, 0, (size_t)fr.dst_cap, &used, fp, lit, options);
+			if (v >= 0) {
+				r.status = (used == fr.src_len) ? LA_ST_OK : LA_ST_ZSTD_CORRUPT;	/* the host cut the frame here */
+				r.out_len = (uint64_t)v;
+			} else {
+				r.status = v == -2 ? LA_ST_ZSTD_OUT_FULL : v == -3 ? LA_ST_ZSTD_TRUNCATED : v == -4 ? LA_ST_ZSTD_BAD_CHECKSUM :
+				    v == -5 ? LA_ST_ZSTD_UNSUPPORTED : v == -6 ? LA_ST_ZSTD_WINDOW : v == -7 ? LA_ST_ZSTD_DICTIONARY : LA_ST_ZSTD_CORRUPT;
+			}
+		}
+		results[i] = r;
+	}
+}
+
+static uint32_t zstd_lanes(uint32_t n) { return n < ZSTD_MAX_LANES ? n : ZSTD_MAX_LANES; }
+
+uint64_t la_zstd_workspace_bytes(uint32_t n_frames)
+{
+	return (uint64_t)zstd_lanes(n_frames) * ZSTD_WS_STRIDE;
+}
+
+void la_launch_zstd_frames(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes, const la_zstd_frame *d_frames, uint32_t n,
+    uint8_t *d_dst, uint64_t dst_cap, la_zstd_result *d_results, uint8_t *ws, uint32_t options)
+{
+	if (n == 0) return;
+	const uint32_t lanes = zstd_lanes(n);
+	static_assert(sizeof(zframe) <= 12288, "zframe must fit in front of the literals buffer");
+	hipLaunchKernelGGL(zstd_frames_kernel, dim3((lanes + 63u) / 64u), dim3(64), 0, s, d_src, src_bytes, d_frames, n, d_dst, dst_cap,
+	    d_results, ws, lanes, options);
+}

@@ -1,0 +1,288 @@
+/*
+ * la_filter_zstd.c -- the zstd read filter on the MI355X data plane.
+ *
+ * Mirrors libarchive/archive_read_support_filter_zstd.c: the same bidder (zstd.c:107-131: 32 bits on the frame
+ * magic or on a skippable-frame magic), filter code and name (ARCHIVE_FILTER_ZSTD, "zstd"), vtable shape
+ * (read / close) and error strings ("Truncated zstd input", zstd.c:213-217; "Zstd decompression failed: %s" with
+ * libzstd's error names, zstd.c:226-231).  Where the reference feeds ZSTD_decompressStream whatever
+ * __archive_read_filter_ahead returns and hands out one ZSTD_DStreamOutSize() buffer per read, this filter gathers
+ * a window of WHOLE frames (la_zstd_index_build: frame and block headers only), decodes them in one
+ * la_gpu_zstd_decode call -- one frame per lane -- and hands out one frame per read.  Bytes in front of an error are
+ * delivered first, as the reference's loop does.  There is no CPU fallback.
+ */
+#include "la_read_private.h"
+#include "la_host.h"
+#include <errno.h>
+#include <stdlib.h>
+#include <string.h>
+
+struct zstd_private {
+	la_gpu_ctx *gpu;
+	size_t batch_bytes;		/* compressed bytes gathered per window */
+	uint64_t out_budget;		/* decoded bytes asked for per window */
+	/* stage: compressed bytes not decoded yet */
+	uint8_t *stage; size_t stage_len, stage_cap;
+	int upstream_eof;
+	/* one decoded window */
+	la_zstd_frame *frames; uint32_t frames_cap;
+	la_zstd_result *results;
+	uint8_t *out; size_t out_cap;		/* pinned */
+	void *d_src, *d_dst, *d_frames, *d_results;
+	size_t d_src_cap, d_dst_cap, d_tab_cap;
+	uint32_t n, next;			/* frames of the window / next to hand out */
+	int end_kind;				/* what follows the window's last frame */
+	int finished;				/* error or end already reported */
+	int n_windows_started;
+	int64_t total_out;
+};
+
+static int zstd_reader_bid(struct archive_read_filter_bidder *, struct archive_read_filter *);
+static int zstd_reader_init(struct archive_read_filter *);
+static ssize_t zstd_filter_read(struct archive_read_filter *, const void **);
+static int zstd_filter_close(struct archive_read_filter *);
+
+static const struct archive_read_filter_bidder_vtable zstd_bidder_vtable = {
+	.bid = zstd_reader_bid,
+	.init = zstd_reader_init,
+};
+static const struct archive_read_filter_vtable zstd_reader_vtable = {
+	.read = zstd_filter_read,
+	.close = zstd_filter_close,
+};
+
+int archive_read_support_filter_zstd(struct archive *_a)
+{
+	struct archive_read *a = (struct archive_read *)_a;
+	if (__archive_read_register_bidder(a, NULL, "zstd", &zstd_bidder_vtable) != ARCHIVE_OK)
+		return ARCHIVE_FATAL;
+	return ARCHIVE_OK;
+}
+
+static int zstd_reader_bid(struct archive_read_filter_bidder *self, struct archive_read_filter *filter)
+{
+	ssize_t avail;
+	(void)self;
+	const unsigned char *p = __archive_read_filter_ahead(filter, 4, &avail);
+	if (p == NULL)
+		return 0;
+	return la_zstd_bid_bytes(p, 4);
+}
+
+static int zstd_reader_init(struct archive_read_filter *self)
+{
+	self->code = ARCHIVE_FILTER_ZSTD;
+	self->name = "zstd";
+	struct zstd_private *st = calloc(1, sizeof(*st));
+	if (st == NULL) {
+		archive_set_error(&self->archive->archive, ENOMEM, "Can't allocate data for zstd decompression");
+		return ARCHIVE_FATAL;
+	}
+	const char *dev = getenv("LA_GPU_DEVICE");
+	const char *bm = getenv("LA_GPU_BATCH_MIB");
+	st->batch_bytes = (size_t)(bm && atoi(bm) > 0 ? atoi(bm) : 256) << 20;
+	const char *ob = getenv("LA_GPU_OUT_BUDGET_MIB");
+	st->out_budget = (uint64_t)(ob && atoi(ob) > 0 ? atoi(ob) : 4096) << 20;
+	int rc = la_gpu_open(dev ? atoi(dev) : 0, &st->gpu);
+	if (rc != LA_OK) {
+		archive_set_error(&self->archive->archive, ARCHIVE_ERRNO_MISC,
+		    "Can't initialize zstd GPU data plane (la_gpu_open: %d); no CPU fallback is built", rc);
+		free(st);
+		return ARCHIVE_FATAL;
+	}
+	self->data = st;
+	self->vtable = &zstd_reader_vtable;
+	return ARCHIVE_OK;
+}
+
+static int gpu_fail(struct archive_read_filter *self, struct zstd_private *st, const char *what)
+{
+	archive_set_error(&self->archive->archive, ARCHIVE_ERRNO_MISC,
+	    "zstd GPU data plane: %s failed: %s", what, la_gpu_last_error(st->gpu));
+	st->finished = 1;
+	return ARCHIVE_FATAL;
+}
+
+static int grow_dev(struct zstd_private *st, void **p, size_t *cap, size_t need)
+{
+	if (need <= *cap)
+		return LA_OK;
+	if (*p)
+		la_gpu_free(st->gpu, *p);
+	*p = NULL;
+	*cap = 0;
+	need = (need + (need >> 2) + 0xFFFFFu) & ~(size_t)0xFFFFFu;
+	int rc = la_gpu_malloc(st->gpu, p, need);
+	if (rc == LA_OK)
+		*cap = need;
+	return rc;
+}
+
+/* Pull upstream into the stage until it holds a window's worth (or upstream ends). */
+static int zstd_fill(struct archive_read_filter *self, struct zstd_private *st, size_t want)
+{
+	while (!st->upstream_eof && st->stage_len < want) {
+		ssize_t avail;
+		const void *up = __archive_read_filter_ahead(self->upstream, 1, &avail);
+		if (up == NULL) {
+			if (avail < 0)
+				return (int)avail;
+			st->upstream_eof = 1;
+			break;
+		}
+		size_t n = (size_t)avail;
+		if (n > want - st->stage_len)
+			n = want - st->stage_len;
+		if (st->stage_len + n > st->stage_cap) {
+			size_t nc = st->stage_cap ? st->stage_cap : (1u << 20);
+			while (nc < st->stage_len + n)
+				nc *= 2;
+			uint8_t *np = realloc(st->stage, nc);
+			if (np == NULL) {
+				archive_set_error(&self->archive->archive, ENOMEM, "Can't allocate data for zstd decompression");
+				return ARCHIVE_FATAL;
+			}
+			st->stage = np;
+			st->stage_cap = nc;
+		}
+		memcpy(st->stage + st->stage_len, up, n);
+		st->stage_len += n;
+		__archive_read_filter_consume(self->upstream, (int64_t)n);
+	}
+	return ARCHIVE_OK;
+}
+
+/* Gather, index, decode one window.  Returns ARCHIVE_OK with st->n frames ready (possibly 0) or an error. */
+static int zstd_next_window(struct archive_read_filter *self, struct zstd_private *st)
+{
+	la_zstd_index_result ir;
+	size_t want = st->batch_bytes;
+	for (;;) {
+		int r = zstd_fill(self, st, want);
+		if (r != ARCHIVE_OK)
+			return r;
+		if (st->frames_cap == 0) {
+			st->frames_cap = 1u << 16;
+			st->frames = malloc(sizeof(la_zstd_frame) * st->frames_cap);
+			st->results = malloc(sizeof(la_zstd_result) * st->frames_cap);
+			if (!st->frames || !st->results) {
+				archive_set_error(&self->archive->archive, ENOMEM, "Can't allocate data for zstd decompression");
+				return ARCHIVE_FATAL;
+			}
+		}
+		la_zstd_index_build(st->stage, st->stage_len, st->upstream_eof, st->out_budget, st->frames, st->frames_cap, &ir);
+		if (ir.n_frames == 0 && ir.end_kind == LA_END_NEED_MORE && !ir.window_full && !st->upstream_eof) {
+			want = st->stage_len * 2 > want ? st->stage_len * 2 : want * 2;	/* one frame larger than the window: gather on */
+			continue;
+		}
+		break;
+	}
+	st->n = ir.n_frames;
+	st->next = 0;
+	st->end_kind = ir.end_kind;
+	if (st->n) {
+		const size_t tab = sizeof(la_zstd_frame) * st->n, rtab = sizeof(la_zstd_result) * st->n;
+		if (grow_dev(st, &st->d_src, &st->d_src_cap, (size_t)ir.consumed + 64) != LA_OK) return gpu_fail(self, st, "la_gpu_malloc");
+		if (grow_dev(st, &st->d_dst, &st->d_dst_cap, (size_t)ir.dst_bytes + 64) != LA_OK) return gpu_fail(self, st, "la_gpu_malloc");
+		if (tab + rtab > st->d_tab_cap) {
+			if (st->d_frames) la_gpu_free(st->gpu, st->d_frames);
+			st->d_frames = NULL;
+			st->d_tab_cap = 0;
+			if (la_gpu_malloc(st->gpu, &st->d_frames, 2 * (tab + rtab)) != LA_OK) return gpu_fail(self, st, "la_gpu_malloc");
+			st->d_tab_cap = 2 * (tab + rtab);
+		}
+		st->d_results = (uint8_t *)st->d_frames + ((tab + 15u) & ~(size_t)15u);
+		if ((size_t)ir.dst_bytes > st->out_cap) {
+			if (st->out) la_gpu_free_host(st->gpu, st->out);
+			st->out = NULL;
+			st->out_cap = 0;
+			void *hp = NULL;
+			const size_t nc = ((size_t)ir.dst_bytes + ((size_t)ir.dst_bytes >> 2) + 0xFFFFFu) & ~(size_t)0xFFFFFu;
+			if (la_gpu_malloc_host(st->gpu, &hp, nc) != LA_OK) return gpu_fail(self, st, "la_gpu_malloc_host");
+			st->out = hp;
+			st->out_cap = nc;
+		}
+		if (la_gpu_memcpy_h2d(st->gpu, st->d_src, st->stage, ir.consumed) != LA_OK) return gpu_fail(self, st, "la_gpu_memcpy_h2d");
+		if (la_gpu_memcpy_h2d(st->gpu, st->d_frames, st->frames, tab) != LA_OK) return gpu_fail(self, st, "la_gpu_memcpy_h2d");
+		la_zstd_batch bt;
+		memset(&bt, 0, sizeof(bt));
+		bt.d_src = st->d_src; bt.src_bytes = ir.consumed;
+		bt.d_frames = st->d_frames; bt.n_frames = st->n;
+		bt.d_dst = st->d_dst; bt.dst_cap = ir.dst_bytes;
+		bt.d_results = st->d_results;
+		if (la_gpu_zstd_decode(st->gpu, &bt) != LA_OK) return gpu_fail(self, st, "la_gpu_zstd_decode");
+		if (la_gpu_memcpy_d2h(st->gpu, st->results, st->d_results, rtab) != LA_OK) return gpu_fail(self, st, "la_gpu_memcpy_d2h");
+		if (ir.dst_bytes && la_gpu_memcpy_d2h(st->gpu, st->out, st->d_dst, ir.dst_bytes) != LA_OK) return gpu_fail(self, st, "la_gpu_memcpy_d2h");
+		if (la_gpu_sync(st->gpu) != LA_OK) return gpu_fail(self, st, "la_gpu_sync");
+	}
+	/* keep what the window did not cover */
+	memmove(st->stage, st->stage + ir.consumed, st->stage_len - (size_t)ir.consumed);
+	st->stage_len -= (size_t)ir.consumed;
+	return ARCHIVE_OK;
+}
+
+static ssize_t zstd_filter_read(struct archive_read_filter *self, const void **p)
+{
+	struct zstd_private *st = (struct zstd_private *)self->data;
+	*p = NULL;
+	if (st->finished)
+		return 0;
+	for (;;) {
+		while (st->next < st->n) {
+			const uint32_t i = st->next++;
+			const la_zstd_result *r = &st->results[i];
+			if (r->status != LA_ST_OK) {
+				archive_set_error(&self->archive->archive, ARCHIVE_ERRNO_MISC, "%s", la_status_message(r->status));
+				st->finished = 1;
+				return ARCHIVE_FATAL;
+			}
+			if (r->out_len == 0)
+				continue;	/* (the reference's loop goes on over an empty frame: zstd.c:196-239) */
+			*p = st->out + st->frames[i].dst_off;
+			st->total_out += (int64_t)r->out_len;
+			return (ssize_t)r->out_len;
+		}
+		/* the window is handed out: what came behind its last frame? */
+		if (st->n_windows_started) {
+			const char *m = NULL;
+			switch (st->end_kind) {
+			case LA_END_TRUNCATED: m = "Truncated zstd input"; break;	/* zstd.c:213-217 */
+			case LA_END_ZSTD_BAD_MAGIC: m = "Zstd decompression failed: Unknown frame descriptor"; break;
+			case LA_END_ZSTD_BAD_BLOCK: m = "Zstd decompression failed: Corrupted block detected"; break;	/* (the device reported the frame) */
+			default: break;
+			}
+			if (m) {
+				archive_set_error(&self->archive->archive, ARCHIVE_ERRNO_MISC, "%s", m);
+				st->finished = 1;
+				return ARCHIVE_FATAL;
+			}
+			if (st->end_kind == LA_END_EOF) {	/* end of input on a frame boundary (zstd.c:208-211) */
+				st->finished = 1;
+				return 0;
+			}
+		}
+		st->n_windows_started = 1;
+		int r = zstd_next_window(self, st);
+		if (r != ARCHIVE_OK)
+			return r;
+	}
+}
+
+static int zstd_filter_close(struct archive_read_filter *self)
+{
+	struct zstd_private *st = (struct zstd_private *)self->data;
+	if (st == NULL)
+		return ARCHIVE_OK;
+	if (st->gpu) {
+		if (st->d_src) la_gpu_free(st->gpu, st->d_src);
+		if (st->d_dst) la_gpu_free(st->gpu, st->d_dst);
+		if (st->d_frames) la_gpu_free(st->gpu, st->d_frames);
+		if (st->out) la_gpu_free_host(st->gpu, st->out);
+		la_gpu_close(st->gpu);
+	}
+	free(st->stage);
+	free(st->frames);
+	free(st->results);
+	free(st);
+	self->data = NULL;
+	return ARCHIVE_OK;
+}

@@ -341,6 +341,14 @@ const char *la_status_message(uint32_t st)
 	case LA_ST_GZ_TRUNCATED: return "truncated gzip input";
 	case LA_ST_GZ_BAD_CRC: return "gzip member CRC32 mismatch";
 	case LA_ST_GZ_BAD_ISIZE: return "gzip member ISIZE mismatch";
+	/* zstd.c:226-231 "Zstd decompression failed: %s" with libzstd's ZSTD_getErrorName() text */
+	case LA_ST_ZSTD_CORRUPT: return "Zstd decompression failed: Corrupted block detected";
+	case LA_ST_ZSTD_TRUNCATED: return "Truncated zstd input";
+	case LA_ST_ZSTD_BAD_CHECKSUM: return "Zstd decompression failed: Restored data doesn't match checksum";
+	case LA_ST_ZSTD_OUT_FULL: return "Zstd decompression failed: Corrupted block detected";
+	case LA_ST_ZSTD_UNSUPPORTED: return "Zstd decompression failed: Unsupported frame parameter";
+	case LA_ST_ZSTD_WINDOW: return "Zstd decompression failed: Frame requires too much memory for decoding";
+	case LA_ST_ZSTD_DICTIONARY: return "Zstd decompression failed: Dictionary mismatch";
 	default: return "unknown device status";
 	}
 }

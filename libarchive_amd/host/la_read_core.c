@@ -118,6 +118,7 @@ int archive_read_support_filter_all(struct archive *a)
 	/* archive_read_support_filter_all.c:40-84, restricted to the filters this host carries */
 	archive_read_support_filter_gzip(a);
 	archive_read_support_filter_lz4(a);
+	archive_read_support_filter_zstd(a);
 	archive_clear_error(a);
 	return ARCHIVE_OK;
 }

@@ -272,3 +272,22 @@ int la_gpu_gzip_compress(la_gpu_ctx *c, const la_gzc_batch *bt)
 	*bt->d_out_bytes = o;
 	return LA_OK;
 }
+
+/* zstd: one oracle stream decode per frame (test stand-in, CPU only) */
+uint64_t la_gpu_zstd_workspace_bytes(uint32_t n) { (void)n; return 0; }
+int la_gpu_zstd_decode(la_gpu_ctx *c, const la_zstd_batch *bt)
+{
+	(void)c;
+	for (uint32_t i = 0; i < bt->n_frames; i++) {
+		const la_zstd_frame *f = &bt->d_frames[i];
+		size_t out = 0;
+		char msg[96];
+		const int rc = orc_zstd_stream_decode(bt->d_src + f->src_off, (size_t)f->src_len, bt->d_dst + f->dst_off,
+		    (size_t)f->dst_cap, &out, msg, sizeof(msg));
+		bt->d_results[i].reserved = 0;
+		bt->d_results[i].out_len = rc == 0 ? out : 0;
+		bt->d_results[i].status = rc == 0 ? LA_ST_OK : (rc == -2 ? LA_ST_ZSTD_OUT_FULL :
+		    (msg[0] == 'T' ? LA_ST_ZSTD_TRUNCATED : LA_ST_ZSTD_CORRUPT));
+	}
+	return LA_OK;
+}

@@ -17,7 +17,7 @@ import streams as S
 pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_fixtures")
-MANIFEST = json.load(open(os.path.join(GOLD, "manifest.json")))
+MANIFEST = [e for e in json.load(open(os.path.join(GOLD, "manifest.json"))) if e["codec"] in ("lz4", "gzip")]
 
 
 def oracle_tuple(img, codec):

@@ -62,6 +62,16 @@ from test_gpu_tar import (  # noqa: E402,F401
 )
 
 
+from test_gpu_zstd import (  # noqa: E402,F401
+    test_zstd_reference_fixtures_through_the_api,
+    test_zstd_compat_tars_list_like_the_reference_test,
+    test_zstd_every_level_and_shape,
+    test_zstd_many_frames_with_skippable_frames_and_small_reads,
+    test_zstd_stream_that_starts_with_a_skippable_frame,
+    test_zstd_truncated_and_damaged_streams,
+    test_zstd_garbage_behind_a_frame,
+)
+
 from test_gpu_zip import (  # noqa: E402,F401
     test_reference_zip_fixtures,
     test_written_archives_many_entries,

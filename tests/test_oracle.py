@@ -13,7 +13,7 @@ import oracle_lib as O
 import streams as S
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_fixtures")
-MANIFEST = json.load(open(os.path.join(GOLD, "manifest.json")))
+MANIFEST = [e for e in json.load(open(os.path.join(GOLD, "manifest.json"))) if e["codec"] in ("lz4", "gzip")]
 
 
 def test_hash_kats():
