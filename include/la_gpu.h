@@ -290,6 +290,7 @@ typedef struct la_zstd_batch {
 } la_zstd_batch;
 
 #define LA_ZSTD_OPT_NO_VERIFY 1u	/* skip the content checksum */
+#define LA_ZSTD_OPT_LANE_KERNEL 2u	/* first-generation kernel, one LANE per frame (default: one wave per frame); same results, kept as a cross-check */
 
 uint64_t la_gpu_zstd_workspace_bytes(uint32_t n_frames);
 int      la_gpu_zstd_decode(la_gpu_ctx *ctx, const la_zstd_batch *batch);

@@ -5,12 +5,23 @@
  * compressed blocks (Huffman literals in 1 or 4 streams with direct or FSE-coded weights, FSE sequences with
  * predefined / RLE / described / repeated tables, repeat offsets), and the XXH64 content checksum (RFC 8878).
  *
- * Parallelism is ACROSS frames only: one lane decodes one frame from its first byte to its checksum (a frame is one
- * serial chain: every block may reach back into the previous ones, entropy tables and repeat offsets carry over).
- * Tables and the literals buffer of a lane live in a workspace slot in HBM (144 KiB per lane).  That is the shape of
- * pzstd output and of seekable / chunked .zst files (many frames); a one-frame .zst runs on ONE lane and is this
- * design's worst case, like a one-member .gz (DESIGN.md known limits).  No attempt at speed yet: byte-wise bit
- * reader, byte-wise match copies.
+ * Parallelism is ACROSS frames: a frame is one serial chain (every block may reach back into the previous ones,
+ * entropy tables and repeat offsets carry over).  That is the shape of pzstd output and of seekable / chunked .zst
+ * files; a one-frame .zst runs on one wave and is this design's worst case, like a one-member .gz.
+ *
+ *   zstd_frames_wave_kernel (default)  one WAVE per frame.  All 64 lanes run the same decoder on the same frame
+ *       (uniform control flow: every lane computes the same header, table and sequence values, so nothing is
+ *       broadcast and nothing diverges); the entropy tables live in LDS (10 KiB per wave), the bit streams are read
+ *       through a 64-bit register window, and the byte moving is split over the lanes: raw / RLE blocks, literal
+ *       runs and matches (an overlapping match reads position k mod offset of the bytes in front of it, so all
+ *       its bytes go out at once), the four Huffman streams on four lanes, XXH64's four accumulators on four lanes.
+ *       One s_waitcnt vmcnt(0) per sequence orders a match's loads behind the stores it may read.
+ *   zstd_frames_kernel (LA_ZSTD_OPT_LANE_KERNEL)  the first form, one LANE per frame with its tables in an HBM
+ *       workspace slot: same results, kept as a cross-check.
+ * Measured (tools/measure_zstd.py, profiles/r02_zstd.txt): 16 384 frames of 64 KiB at level 3 decode at 12.6 GiB/s
+ * resident in HBM (lane form: 6.1) against 2.8 GiB/s for libzstd on one host core.  A sequence costs two to three
+ * dependent trips to L2 / HBM (literal run, fence, match); decoding a block's sequences into LDS first and executing
+ * them with one lane per sequence, as la_lz4_wide.hip does, is the next step.
  */
 #include "la_dev.h"
 
@@ -62,6 +73,73 @@ __device__ static void dev_fill(uint8_t *d, uint8_t v, size_t n)
 	size_t i = 0;
 	for (; i + 8 <= n; i += 8) __builtin_memcpy(d + i, &w, 8);
 	for (; i < n; i++) d[i] = v;
+}
+
+/* ---- wave form: the same decoder run by all 64 lanes of a wave on ONE frame (uniform control flow, every lane
+ * computes the same header / table / sequence values), with the byte moving split over the lanes ---- */
+__device__ static void wave_fence() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+template <bool W> __device__ static void t_copy(uint8_t *d, const uint8_t *s, size_t n)
+{
+	if (!W) { dev_copy(d, s, n); return; }
+	const size_t lane = __lane_id(), body = n & ~(size_t)7;
+	for (size_t i = lane * 8; i < body; i += 512) { uint64_t v; __builtin_memcpy(&v, s + i, 8); __builtin_memcpy(d + i, &v, 8); }
+	for (size_t i = body + lane; i < n; i += 64) d[i] = s[i];
+}
+template <bool W> __device__ static void t_fill(uint8_t *d, uint8_t v, size_t n)
+{
+	if (!W) { dev_fill(d, v, n); return; }
+	const uint64_t w = 0x0101010101010101ull * v;
+	const size_t lane = __lane_id(), body = n & ~(size_t)7;
+	for (size_t i = lane * 8; i < body; i += 512) __builtin_memcpy(d + i, &w, 8);
+	for (size_t i = body + lane; i < n; i += 64) d[i] = v;
+}
+/* match of ml bytes at dst[out..] from offset bytes back; every source byte of an overlapping match (offset < ml)
+ * is one of the `offset` bytes in front of it, so the wave form copies all positions at once */
+template <bool W> __device__ static void t_match(uint8_t *dst, size_t out, uint32_t offset, uint32_t ml)
+{
+	if (!W) {
+		for (uint32_t k = 0; k < ml; k++) dst[out + k] = dst[out + k - offset];
+		return;
+	}
+	const uint32_t lane = __lane_id();
+	const uint8_t *s = dst + out - offset;
+	if (offset >= ml) {
+		for (uint32_t k = lane; k < ml; k += 64) dst[out + k] = s[k];
+	} else {
+		for (uint32_t k = lane; k < ml; k += 64) dst[out + k] = s[k % offset];
+	}
+}
+/* XXH64, wave form: lane j & 3 runs accumulator j over the 32-byte stripes, the rest is uniform */
+__device__ static uint64_t wave_xxh64(const uint8_t *p, size_t len, uint64_t seed)
+{
+	const uint8_t *end = p + len;
+	uint64_t h;
+	if (len >= 32) {
+		const uint32_t j = __lane_id() & 3u;
+		uint64_t v = j == 0 ? seed + P64_1 + P64_2 : (j == 1 ? seed + P64_2 : (j == 2 ? seed : seed - P64_1));
+		const size_t stripes = len / 32;
+		const uint8_t *q = p + 8 * j;
+#pragma unroll 8
+		for (size_t s = 0; s < stripes; s++)
+			v = xxh64_round(v, rd64(q + 32 * s));
+		uint64_t a[4];
+		for (int k = 0; k < 4; k++) {
+			const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, k, 64), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), k, 64);
+			a[k] = (uint64_t)lo | ((uint64_t)hi << 32);
+		}
+		h = rotl64(a[0], 1) + rotl64(a[1], 7) + rotl64(a[2], 12) + rotl64(a[3], 18);
+		h = xxh64_merge(h, a[0]); h = xxh64_merge(h, a[1]); h = xxh64_merge(h, a[2]); h = xxh64_merge(h, a[3]);
+		p += stripes * 32;
+	} else {
+		h = seed + P64_5;
+	}
+	h += (uint64_t)len;
+	while (p + 8 <= end) { h ^= xxh64_round(0, rd64(p)); h = rotl64(h, 27) * P64_1 + P64_4; p += 8; }
+	if (p + 4 <= end) { h ^= (uint64_t)rd32(p) * P64_1; h = rotl64(h, 23) * P64_2 + P64_3; p += 4; }
+	while (p < end) { h ^= (uint64_t)(*p++) * P64_5; h = rotl64(h, 11) * P64_1; }
+	h ^= h >> 33; h *= P64_2; h ^= h >> 29; h *= P64_3; h ^= h >> 32;
+	return h;
 }
 
 /* ---- bit readers ---- */
@@ -227,12 +305,41 @@ __device__ static int huf_read(huf_tab *h, const uint8_t *src, size_t len)	/* re
 	return (int)used;
 }
 
+/* windowed reader of a backward stream: 64 bits of the stream in a register, one unaligned 8-byte load per refill
+ * (the byte-wise bits_at above costs six dependent-latency loads per read) */
+struct rbits { const uint8_t *src; size_t len; uint64_t win; int64_t lo; };
+__device__ static void rb_init(rbits &b, const uint8_t *src, size_t len) { b.src = src; b.len = len; b.win = 0; b.lo = (int64_t)1 << 62; }
+/* n (<= 32) bits at position p (may be negative: zero bits), p + n <= 8 * len */
+__device__ static uint32_t rb_at(rbits &b, int64_t p, unsigned n)
+{
+	if (n == 0) return 0;
+	if (p < b.lo || p + (int64_t)n > b.lo + 64) {
+		const int64_t hi_byte = (p + (int64_t)n + 7) >> 3, lo_byte = hi_byte - 8;	/* the window ends just above the bits asked for */
+		if (lo_byte >= 0 && (uint64_t)hi_byte <= b.len) {
+			b.win = rd64(b.src + lo_byte);
+		} else {
+			uint64_t v = 0;
+			for (int i = 0; i < 8; i++) {
+				const int64_t byte = lo_byte + i;
+				if (byte >= 0 && (uint64_t)byte < b.len) v |= (uint64_t)b.src[byte] << (8 * i);
+			}
+			b.win = v;
+		}
+		b.lo = lo_byte * 8;
+	}
+	return (uint32_t)((b.win >> (unsigned)(p - b.lo)) & ((n >= 32) ? 0xFFFFFFFFull : ((1ull << n) - 1)));
+}
+__device__ static uint32_t rb_read(rbits &b, int64_t *pos, unsigned n) { *pos -= n; return rb_at(b, *pos, n); }
+
 __device__ static int huf_stream(const huf_tab *h, const uint8_t *src, size_t len, uint8_t *out, size_t n)
 {
 	int64_t pos = rev_init(src, len);
 	if (pos < 0) return -1;
+	rbits b;
+	rb_init(b, src, len);
+	const unsigned mb = (unsigned)h->maxbits;
 	for (size_t i = 0; i < n; i++) {
-		const uint32_t idx = bits_at(src, len, pos - h->maxbits, (unsigned)h->maxbits);
+		const uint32_t idx = rb_at(b, pos - mb, mb);
 		out[i] = h->sym[idx];
 		pos -= h->nbits[idx];
 		if (pos < 0) return -1;
@@ -275,7 +382,7 @@ __device__ static int seq_table(fse_tab *t, int *have, int mode, const uint8_t *
 #define ZBLOCK_MAX (128u * 1024u)
 
 /* one compressed block; returns bytes produced or -1 */
-__device__ static int64_t zstd_block(zframe *f, const uint8_t *src, size_t len, uint8_t *dst, size_t dst_pos, size_t dst_cap)
+template <bool W> __device__ static int64_t zstd_block(zframe *f, const uint8_t *src, size_t len, uint8_t *dst, size_t dst_pos, size_t dst_cap)
 {
 	if (len < 1) return -1;	/* (libzstd: a compressed block needs at least a literals header) */
 	/* ---- literals section ---- */
@@ -307,8 +414,8 @@ __device__ static int64_t zstd_block(zframe *f, const uint8_t *src, size_t len, 
 	if (regen > ZBLOCK_MAX) return -1;
 	const uint8_t *p = src + hl;
 	size_t left = len - hl;
-	if (ltype == 0) { if (regen > left) return -1; dev_copy(f->lit, p, regen); p += regen; left -= regen; }
-	else if (ltype == 1) { if (left < 1) return -1; dev_fill(f->lit, p[0], regen); p += 1; left -= 1; }
+	if (ltype == 0) { if (regen > left) return -1; t_copy<W>(f->lit, p, regen); p += regen; left -= regen; }
+	else if (ltype == 1) { if (left < 1) return -1; t_fill<W>(f->lit, p[0], regen); p += 1; left -= 1; }
 	else {
 		if (comp > left) return -1;
 		const uint8_t *hp = p; size_t hleft = comp;
@@ -318,7 +425,13 @@ __device__ static int64_t zstd_block(zframe *f, const uint8_t *src, size_t len, 
 			f->have_huf = 1; hp += c; hleft -= (size_t)c;
 		} else if (!f->have_huf) return -1;
 		if (streams == 1) {
-			if (huf_stream(&f->huf, hp, hleft, f->lit, regen) < 0) return -1;
+			if (!W) {
+				if (huf_stream(&f->huf, hp, hleft, f->lit, regen) < 0) return -1;
+			} else {
+				int bad = 0;
+				if (__lane_id() == 0) bad = huf_stream(&f->huf, hp, hleft, f->lit, regen) < 0;
+				if (__ballot(bad) != 0) return -1;
+			}
 		} else {
 			if (hleft < 6) return -1;
 			const size_t s1 = hp[0] | ((size_t)hp[1] << 8), s2 = hp[2] | ((size_t)hp[3] << 8), s3 = hp[4] | ((size_t)hp[5] << 8);
@@ -326,14 +439,26 @@ __device__ static int64_t zstd_block(zframe *f, const uint8_t *src, size_t len, 
 			const size_t s4 = hleft - 6 - s1 - s2 - s3, q = (regen + 3) / 4;
 			if (3 * q > regen) return -1;
 			hp += 6;
-			if (huf_stream(&f->huf, hp, s1, f->lit, q) < 0) return -1;
-			if (huf_stream(&f->huf, hp + s1, s2, f->lit + q, q) < 0) return -1;
-			if (huf_stream(&f->huf, hp + s1 + s2, s3, f->lit + 2 * q, q) < 0) return -1;
-			if (huf_stream(&f->huf, hp + s1 + s2 + s3, s4, f->lit + 3 * q, regen - 3 * q) < 0) return -1;
+			if (!W) {
+				if (huf_stream(&f->huf, hp, s1, f->lit, q) < 0) return -1;
+				if (huf_stream(&f->huf, hp + s1, s2, f->lit + q, q) < 0) return -1;
+				if (huf_stream(&f->huf, hp + s1 + s2, s3, f->lit + 2 * q, q) < 0) return -1;
+				if (huf_stream(&f->huf, hp + s1 + s2 + s3, s4, f->lit + 3 * q, regen - 3 * q) < 0) return -1;
+			} else {	/* the four streams on four lanes */
+				const uint32_t ln = __lane_id();
+				int bad = 0;
+				if (ln < 4) {
+					const size_t so = ln == 0 ? 0 : (ln == 1 ? s1 : (ln == 2 ? s1 + s2 : s1 + s2 + s3));
+					const size_t sl_ = ln == 0 ? s1 : (ln == 1 ? s2 : (ln == 2 ? s3 : s4));
+					bad = huf_stream(&f->huf, hp + so, sl_, f->lit + ln * q, ln == 3 ? regen - 3 * q : q) < 0;
+				}
+				if (__ballot(bad) != 0) return -1;
+			}
 		}
 		p += comp; left -= comp;
 	}
 	/* ---- sequences section ---- */
+	if (W) wave_fence();	/* the literals are in the buffer */
 	if (left < 1) return -1;
 	size_t nseq = p[0];
 	if (nseq == 0) { p += 1; left -= 1; }
@@ -352,16 +477,18 @@ __device__ static int64_t zstd_block(zframe *f, const uint8_t *src, size_t len, 
 		c = seq_table(&f->ml, &f->have_ml, (modes >> 2) & 3, p, left, 9, 52, ML_DEF, 53, 6); if (c < 0) return -1; p += c; left -= (size_t)c;
 		int64_t pos = rev_init(p, left);
 		if (pos < 0) return -1;
-		uint32_t sl = rev_read(p, left, &pos, (unsigned)f->ll.al);
-		uint32_t so = rev_read(p, left, &pos, (unsigned)f->of.al);
-		uint32_t sm = rev_read(p, left, &pos, (unsigned)f->ml.al);
+		rbits rb;
+		rb_init(rb, p, left);
+		uint32_t sl = rb_read(rb, &pos, (unsigned)f->ll.al);
+		uint32_t so = rb_read(rb, &pos, (unsigned)f->of.al);
+		uint32_t sm = rb_read(rb, &pos, (unsigned)f->ml.al);
 		if (pos < 0) return -1;
 		for (size_t i = 0; i < nseq; i++) {
 			const int oc = f->of.e[so].sym, mc = f->ml.e[sm].sym, lc = f->ll.e[sl].sym;
 			if (oc > 31 || mc > 52 || lc > 35) return -1;
-			const uint32_t ov = (oc ? ((1u << oc) + rev_read(p, left, &pos, (unsigned)oc)) : 1u);
-			const uint32_t ml = ML_BASE[mc] + rev_read(p, left, &pos, ML_BITS[mc]);
-			const uint32_t ll = LL_BASE[lc] + rev_read(p, left, &pos, LL_BITS[lc]);
+			const uint32_t ov = (oc ? ((1u << oc) + rb_read(rb, &pos, (unsigned)oc)) : 1u);
+			const uint32_t ml = ML_BASE[mc] + rb_read(rb, &pos, ML_BITS[mc]);
+			const uint32_t ll = LL_BASE[lc] + rb_read(rb, &pos, LL_BITS[lc]);
 			if (pos < 0) return -1;
 			uint32_t offset;
 			if (ov > 3) {
@@ -378,18 +505,19 @@ __device__ static int64_t zstd_block(zframe *f, const uint8_t *src, size_t len, 
 				}
 			}
 			if (i + 1 < nseq) {
-				sl = f->ll.e[sl].base + rev_read(p, left, &pos, f->ll.e[sl].nbits);
-				sm = f->ml.e[sm].base + rev_read(p, left, &pos, f->ml.e[sm].nbits);
-				so = f->of.e[so].base + rev_read(p, left, &pos, f->of.e[so].nbits);
+				sl = f->ll.e[sl].base + rb_read(rb, &pos, f->ll.e[sl].nbits);
+				sm = f->ml.e[sm].base + rb_read(rb, &pos, f->ml.e[sm].nbits);
+				so = f->of.e[so].base + rb_read(rb, &pos, f->of.e[so].nbits);
 				if (pos < 0) return -1;
 			}
 			/* execute */
 			if (ll > regen - lit_pos) return -1;
 			if (out - dst_pos + ll + ml > ZBLOCK_MAX) return -1;
 			if (out + ll + ml > dst_cap) return -2;
-			dev_copy(dst + out, f->lit + lit_pos, ll); out += ll; lit_pos += ll;
+			t_copy<W>(dst + out, f->lit + lit_pos, ll); out += ll; lit_pos += ll;
+			if (W) wave_fence();	/* this sequence's literals and everything before them are in place */
 			if (offset > out) return -1;
-			for (uint32_t k = 0; k < ml; k++) dst[out + k] = dst[out + k - offset];
+			t_match<W>(dst, out, offset, ml);
 			out += ml;
 		}
 		if (pos != 0) return -1;	/* (libzstd 1.5 checks the exact end too; 1.4.8 does not) */
@@ -397,13 +525,13 @@ __device__ static int64_t zstd_block(zframe *f, const uint8_t *src, size_t len, 
 	const size_t rest = regen - lit_pos;
 	if (out - dst_pos + rest > ZBLOCK_MAX) return -1;
 	if (out + rest > dst_cap) return -2;
-	dev_copy(dst + out, f->lit + lit_pos, rest); out += rest;
+	t_copy<W>(dst + out, f->lit + lit_pos, rest); out += rest;
 	return (int64_t)(out - dst_pos);
 }
 
 /* One frame at src (zstd or skippable).  *consumed = its compressed length.  Returns decoded bytes appended at
  * dst + dst_pos, or -1 format error, -2 dst too small, -3 truncated input. */
-__device__ static int64_t zstd_frame(const uint8_t *src, size_t len, uint8_t *dst, size_t dst_pos, size_t dst_cap, size_t *consumed, zframe *fp, uint8_t *litbuf, uint32_t options)
+template <bool W> __device__ static int64_t zstd_frame(const uint8_t *src, size_t len, uint8_t *dst, size_t dst_pos, size_t dst_cap, size_t *consumed, zframe *fp, uint8_t *litbuf, uint32_t options)
 {
 	if (len < 4) return -3;
 	const uint32_t magic = rd32(src);
@@ -457,14 +585,14 @@ __device__ static int64_t zstd_frame(const uint8_t *src, size_t len, uint8_t *ds
 		if (type == 1) {
 			if (p + 1 > len) return -3;
 			if (out + bsize > dst_cap) return -2;
-			dev_fill(dst + out, src[p], bsize); out += bsize; p += 1;
+			t_fill<W>(dst + out, src[p], bsize); out += bsize; p += 1;
 		} else {
 			if (p + bsize > len) return -3;
 			if (type == 0) {
 				if (out + bsize > dst_cap) return -2;
-				dev_copy(dst + out, src + p, bsize); out += bsize;
+				t_copy<W>(dst + out, src + p, bsize); out += bsize;
 			} else {
-				const int64_t r = zstd_block(&f, src + p, bsize, dst + dst_pos, out - dst_pos, dst_cap - dst_pos);
+				const int64_t r = zstd_block<W>(&f, src + p, bsize, dst + dst_pos, out - dst_pos, dst_cap - dst_pos);
 				if (r < 0) return r;
 				out += (size_t)r;
 			}
@@ -475,7 +603,9 @@ __device__ static int64_t zstd_frame(const uint8_t *src, size_t len, uint8_t *ds
 	if (fcs_len && (uint64_t)(out - dst_pos) != fcs) return -1;
 	if (csum) {
 		if (p + 4 > len) return -3;
-		if (!(options & LA_ZSTD_OPT_NO_VERIFY) && (uint32_t)dev_xxh64(dst + dst_pos, out - dst_pos, 0) != rd32(src + p)) return -4;
+		if (W) wave_fence();
+		if (!(options & LA_ZSTD_OPT_NO_VERIFY) &&
+		    (uint32_t)(W ? wave_xxh64(dst + dst_pos, out - dst_pos, 0) : dev_xxh64(dst + dst_pos, out - dst_pos, 0)) != rd32(src + p)) return -4;
 		p += 4;
 	}
 	*consumed = p;
@@ -501,7 +631,7 @@ __global__ __launch_bounds__(64) void zstd_frames_kernel(const uint8_t *__restri
 		r.status = LA_ST_ZSTD_CORRUPT; r.reserved = 0; r.out_len = 0;
 		if (fr.src_off <= src_bytes && fr.src_len <= src_bytes - fr.src_off && fr.dst_off <= dst_cap && fr.dst_cap <= dst_cap - fr.dst_off) {
 			size_t used = 0;
-			const int64_t v = zstd_frame(src + fr.src_off, (size_t)fr.src_len, dst + fr.dst_off, 0, (size_t)fr.dst_cap, &used, fp, lit, options);
+			const int64_t v = zstd_frame<false>(src + fr.src_off, (size_t)fr.src_len, dst + fr.dst_off, 0, (size_t)fr.dst_cap, &used, fp, lit, options);
 			if (v >= 0) {
 				r.status = (used == fr.src_len) ? LA_ST_OK : LA_ST_ZSTD_CORRUPT;	/* the host cut the frame here */
 				r.out_len = (uint64_t)v;
@@ -514,19 +644,59 @@ __global__ __launch_bounds__(64) void zstd_frames_kernel(const uint8_t *__restri
 	}
 }
 
+#define ZSTD_WAVE_WS_STRIDE (132u * 1024u)	/* per wave: the literals buffer of one block (the tables are in LDS) */
+#define ZSTD_MAX_WAVES 4096u
+
+/* one WAVE per frame: tables in LDS, uniform decode, lane-parallel byte moving, Huffman streams and XXH64 on four lanes */
+__global__ __launch_bounds__(64) void zstd_frames_wave_kernel(const uint8_t *__restrict__ src, uint64_t src_bytes,
+    const la_zstd_frame *__restrict__ frames, uint32_t n, uint8_t *dst, uint64_t dst_cap, la_zstd_result *results,
+    uint8_t *ws, uint32_t waves, uint32_t options)
+{
+	__shared__ zframe sf;
+	const uint32_t w = blockIdx.x;
+	uint8_t *lit = ws + (size_t)w * ZSTD_WAVE_WS_STRIDE;
+	for (uint32_t i = w; i < n; i += waves) {
+		const la_zstd_frame fr = frames[i];
+		la_zstd_result r;
+		r.status = LA_ST_ZSTD_CORRUPT; r.reserved = 0; r.out_len = 0;
+		if (fr.src_off <= src_bytes && fr.src_len <= src_bytes - fr.src_off && fr.dst_off <= dst_cap && fr.dst_cap <= dst_cap - fr.dst_off) {
+			size_t used = 0;
+			const int64_t v = zstd_frame<true>(src + fr.src_off, (size_t)fr.src_len, dst + fr.dst_off, 0, (size_t)fr.dst_cap, &used, &sf, lit, options);
+			if (v >= 0) {
+				r.status = (used == fr.src_len) ? LA_ST_OK : LA_ST_ZSTD_CORRUPT;
+				r.out_len = (uint64_t)v;
+			} else {
+				r.status = v == -2 ? LA_ST_ZSTD_OUT_FULL : v == -3 ? LA_ST_ZSTD_TRUNCATED : v == -4 ? LA_ST_ZSTD_BAD_CHECKSUM :
+				    v == -5 ? LA_ST_ZSTD_UNSUPPORTED : v == -6 ? LA_ST_ZSTD_WINDOW : v == -7 ? LA_ST_ZSTD_DICTIONARY : LA_ST_ZSTD_CORRUPT;
+			}
+		}
+		if (threadIdx.x == 0)
+			results[i] = r;
+		wave_fence();
+	}
+}
+
 static uint32_t zstd_lanes(uint32_t n) { return n < ZSTD_MAX_LANES ? n : ZSTD_MAX_LANES; }
+static uint32_t zstd_waves(uint32_t n) { return n < ZSTD_MAX_WAVES ? n : ZSTD_MAX_WAVES; }
 
 uint64_t la_zstd_workspace_bytes(uint32_t n_frames)
 {
-	return (uint64_t)zstd_lanes(n_frames) * ZSTD_WS_STRIDE;
+	const uint64_t a = (uint64_t)zstd_lanes(n_frames) * ZSTD_WS_STRIDE, b = (uint64_t)zstd_waves(n_frames) * ZSTD_WAVE_WS_STRIDE;
+	return a > b ? a : b;
 }
 
 void la_launch_zstd_frames(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes, const la_zstd_frame *d_frames, uint32_t n,
     uint8_t *d_dst, uint64_t dst_cap, la_zstd_result *d_results, uint8_t *ws, uint32_t options)
 {
 	if (n == 0) return;
-	const uint32_t lanes = zstd_lanes(n);
 	static_assert(sizeof(zframe) <= 12288, "zframe must fit in front of the literals buffer");
-	hipLaunchKernelGGL(zstd_frames_kernel, dim3((lanes + 63u) / 64u), dim3(64), 0, s, d_src, src_bytes, d_frames, n, d_dst, dst_cap,
-	    d_results, ws, lanes, options);
+	if (options & LA_ZSTD_OPT_LANE_KERNEL) {
+		const uint32_t lanes = zstd_lanes(n);
+		hipLaunchKernelGGL(zstd_frames_kernel, dim3((lanes + 63u) / 64u), dim3(64), 0, s, d_src, src_bytes, d_frames, n, d_dst, dst_cap,
+		    d_results, ws, lanes, options);
+	} else {
+		const uint32_t waves = zstd_waves(n);
+		hipLaunchKernelGGL(zstd_frames_wave_kernel, dim3(waves), dim3(64), 0, s, d_src, src_bytes, d_frames, n, d_dst, dst_cap,
+		    d_results, ws, waves, options);
+	}
 }

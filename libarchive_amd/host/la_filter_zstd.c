@@ -209,6 +209,7 @@ static int zstd_next_window(struct archive_read_filter *self, struct zstd_privat
 		bt.d_frames = st->d_frames; bt.n_frames = st->n;
 		bt.d_dst = st->d_dst; bt.dst_cap = ir.dst_bytes;
 		bt.d_results = st->d_results;
+		{ const char *lk = getenv("LA_ZSTD_LANE_KERNEL"); bt.options = (lk && atoi(lk) > 0) ? LA_ZSTD_OPT_LANE_KERNEL : 0u; }
 		if (la_gpu_zstd_decode(st->gpu, &bt) != LA_OK) return gpu_fail(self, st, "la_gpu_zstd_decode");
 		if (la_gpu_memcpy_d2h(st->gpu, st->results, st->d_results, rtab) != LA_OK) return gpu_fail(self, st, "la_gpu_memcpy_d2h");
 		if (ir.dst_bytes && la_gpu_memcpy_d2h(st->gpu, st->out, st->d_dst, ir.dst_bytes) != LA_OK) return gpu_fail(self, st, "la_gpu_memcpy_d2h");

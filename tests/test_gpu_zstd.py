@@ -45,7 +45,10 @@ def test_zstd_compat_tars_list_like_the_reference_test(gpu_ctx):
         assert res.filters[0] == (ARCHIVE_FILTER_ZSTD, "zstd")
 
 
-def test_zstd_every_level_and_shape(gpu_ctx):
+@pytest.mark.parametrize("lane_kernel", [0, 1], ids=["wave-per-frame", "lane-per-frame"])
+def test_zstd_every_level_and_shape(gpu_ctx, monkeypatch, lane_kernel):
+    """both device kernels (LA_ZSTD_OPT_LANE_KERNEL) against the plain bytes and the oracle"""
+    monkeypatch.setenv("LA_ZSTD_LANE_KERNEL", str(lane_kernel))
     z, o = _z(), Z.oracle_lib()
     rnd = random.Random(0x2A)
     for it in range(60):
@@ -85,9 +88,11 @@ def test_zstd_stream_that_starts_with_a_skippable_frame(gpu_ctx):
     assert res.filters[0] == (ARCHIVE_FILTER_ZSTD, "zstd")
 
 
-def test_zstd_truncated_and_damaged_streams(gpu_ctx):
+@pytest.mark.parametrize("lane_kernel", [0, 1], ids=["wave-per-frame", "lane-per-frame"])
+def test_zstd_truncated_and_damaged_streams(gpu_ctx, monkeypatch, lane_kernel):
     """Frames in front of the damage are delivered, then ARCHIVE_FATAL with the reference's strings (zstd.c:213-217,
     :226-231).  The verdict (accept / refuse) is the oracle's; where the stream is accepted the bytes are libzstd's."""
+    monkeypatch.setenv("LA_ZSTD_LANE_KERNEL", str(lane_kernel))
     z, o = _z(), Z.oracle_lib()
     rnd = random.Random(0x99)
     refused = 0
