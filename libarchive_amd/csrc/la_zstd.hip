@@ -15,13 +15,17 @@
  *       through a 64-bit register window, and the byte moving is split over the lanes: raw / RLE blocks, literal
  *       runs and matches (an overlapping match reads position k mod offset of the bytes in front of it, so all
  *       its bytes go out at once), the four Huffman streams on four lanes, XXH64's four accumulators on four lanes.
- *       One s_waitcnt vmcnt(0) per sequence orders a match's loads behind the stores it may read.
+ *       Sequences go 64 at a time: the wave decodes them (uniform, lane j keeps sequence j), then every lane copies its
+ *       own literal run, one s_waitcnt vmcnt(0), and the matches follow in ballot rounds (a source that reaches into
+ *       the group waits for the lanes whose sequences it touches, found with two lower bounds over the lanes' end
+ *       positions; the scheme of la_lz4_wide.hip's in-order path).
  *   zstd_frames_kernel (LA_ZSTD_OPT_LANE_KERNEL)  the first form, one LANE per frame with its tables in an HBM
  *       workspace slot: same results, kept as a cross-check.
- * Measured (tools/measure_zstd.py, profiles/r02_zstd.txt): 16 384 frames of 64 KiB at level 3 decode at 12.6 GiB/s
- * resident in HBM (lane form: 6.1) against 2.8 GiB/s for libzstd on one host core.  A sequence costs two to three
- * dependent trips to L2 / HBM (literal run, fence, match); decoding a block's sequences into LDS first and executing
- * them with one lane per sequence, as la_lz4_wide.hip does, is the next step.
+ * Measured (tools/measure_zstd.py, profiles/r02_zstd.txt): 16 384 frames of 64 KiB at level 3 decode at 17 GiB/s
+ * resident in HBM (lane form: 6.1) against 2.8 GiB/s for libzstd on one host core.  The kernel is bound by
+ * instruction issue in the uniform part: 675 k VALU + 480 k SALU instructions per 64 KiB frame (about 350 per
+ * sequence: 64-bit positions, six checked bit reads), 87 % of a frame's cycles in the 64-sequence decode loop.  Next:
+ * 32-bit block-relative positions and a shift-register bit reader, then one lane per FSE stream of different blocks.
  */
 #include "la_dev.h"
 
@@ -79,14 +83,14 @@ __device__ static void dev_fill(uint8_t *d, uint8_t v, size_t n)
  * computes the same header / table / sequence values), with the byte moving split over the lanes ---- */
 __device__ static void wave_fence() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-template <bool W> __device__ static void t_copy(uint8_t *d, const uint8_t *s, size_t n)
+template <bool W> __device__ __forceinline__ static void t_copy(uint8_t *d, const uint8_t *s, size_t n)
 {
 	if (!W) { dev_copy(d, s, n); return; }
 	const size_t lane = __lane_id(), body = n & ~(size_t)7;
 	for (size_t i = lane * 8; i < body; i += 512) { uint64_t v; __builtin_memcpy(&v, s + i, 8); __builtin_memcpy(d + i, &v, 8); }
 	for (size_t i = body + lane; i < n; i += 64) d[i] = s[i];
 }
-template <bool W> __device__ static void t_fill(uint8_t *d, uint8_t v, size_t n)
+template <bool W> __device__ __forceinline__ static void t_fill(uint8_t *d, uint8_t v, size_t n)
 {
 	if (!W) { dev_fill(d, v, n); return; }
 	const uint64_t w = 0x0101010101010101ull * v;
@@ -96,7 +100,7 @@ template <bool W> __device__ static void t_fill(uint8_t *d, uint8_t v, size_t n)
 }
 /* match of ml bytes at dst[out..] from offset bytes back; every source byte of an overlapping match (offset < ml)
  * is one of the `offset` bytes in front of it, so the wave form copies all positions at once */
-template <bool W> __device__ static void t_match(uint8_t *dst, size_t out, uint32_t offset, uint32_t ml)
+template <bool W> __device__ __forceinline__ static void t_match(uint8_t *dst, size_t out, uint32_t offset, uint32_t ml)
 {
 	if (!W) {
 		for (uint32_t k = 0; k < ml; k++) dst[out + k] = dst[out + k - offset];
@@ -111,7 +115,7 @@ template <bool W> __device__ static void t_match(uint8_t *dst, size_t out, uint3
 	}
 }
 /* XXH64, wave form: lane j & 3 runs accumulator j over the 32-byte stripes, the rest is uniform */
-__device__ static uint64_t wave_xxh64(const uint8_t *p, size_t len, uint64_t seed)
+__device__ __forceinline__ static uint64_t wave_xxh64(const uint8_t *p, size_t len, uint64_t seed)
 {
 	const uint8_t *end = p + len;
 	uint64_t h;
@@ -308,9 +312,9 @@ __device__ static int huf_read(huf_tab *h, const uint8_t *src, size_t len)	/* re
 /* windowed reader of a backward stream: 64 bits of the stream in a register, one unaligned 8-byte load per refill
  * (the byte-wise bits_at above costs six dependent-latency loads per read) */
 struct rbits { const uint8_t *src; size_t len; uint64_t win; int64_t lo; };
-__device__ static void rb_init(rbits &b, const uint8_t *src, size_t len) { b.src = src; b.len = len; b.win = 0; b.lo = (int64_t)1 << 62; }
+__device__ __forceinline__ static void rb_init(rbits &b, const uint8_t *src, size_t len) { b.src = src; b.len = len; b.win = 0; b.lo = (int64_t)1 << 62; }
 /* n (<= 32) bits at position p (may be negative: zero bits), p + n <= 8 * len */
-__device__ static uint32_t rb_at(rbits &b, int64_t p, unsigned n)
+__device__ __forceinline__ static uint32_t rb_at(rbits &b, int64_t p, unsigned n)
 {
 	if (n == 0) return 0;
 	if (p < b.lo || p + (int64_t)n > b.lo + 64) {
@@ -329,9 +333,14 @@ __device__ static uint32_t rb_at(rbits &b, int64_t p, unsigned n)
 	}
 	return (uint32_t)((b.win >> (unsigned)(p - b.lo)) & ((n >= 32) ? 0xFFFFFFFFull : ((1ull << n) - 1)));
 }
-__device__ static uint32_t rb_read(rbits &b, int64_t *pos, unsigned n) { *pos -= n; return rb_at(b, *pos, n); }
+__device__ __forceinline__ static uint32_t rb_read(rbits &b, int64_t *pos, unsigned n) { *pos -= n; return rb_at(b, *pos, n); }
 
-__device__ static int huf_stream(const huf_tab *h, const uint8_t *src, size_t len, uint8_t *out, size_t n)
+/* (a wave-wide form of this reader -- 512 bytes of the stream in one register pair per lane, reads through v_readlane --
+ * was measured slower: 68.8 ms against 58.3 on 16 384 frames; the kernel is bound by instruction issue, not by the refills) */
+__device__ __forceinline__ static void bits_init(rbits &b, const uint8_t *s, size_t l) { rb_init(b, s, l); }
+__device__ __forceinline__ static uint32_t bits_read(rbits &b, int64_t *pos, unsigned n) { *pos -= n; return rb_at(b, *pos, n); }
+
+__device__ __forceinline__ static int huf_stream(const huf_tab *h, const uint8_t *src, size_t len, uint8_t *out, size_t n)
 {
 	int64_t pos = rev_init(src, len);
 	if (pos < 0) return -1;
@@ -348,10 +357,14 @@ __device__ static int huf_stream(const huf_tab *h, const uint8_t *src, size_t le
 }
 
 /* ---- sequences ---- */
-__device__ static const uint32_t LL_BASE[36] = { 0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,18,20,22,24,28,32,40,48,64,128,256,512,1024,2048,4096,8192,16384,32768,65536 };
-__device__ static const uint8_t LL_BITS[36] = { 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,2,2,3,3,4,6,7,8,9,10,11,12,13,14,15,16 };
-__device__ static const uint32_t ML_BASE[53] = { 3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,32,33,34,35,37,39,41,43,47,51,59,67,83,99,131,259,515,1027,2051,4099,8195,16387,32771,65539 };
-__device__ static const uint8_t ML_BITS[53] = { 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,2,2,3,3,4,4,5,7,8,9,10,11,12,13,14,15,16 };
+/* literal-length and match-length codes: baselines and extra bits (RFC 8878 3.1.1.3.2.1.1) */
+struct seq_tabs { uint32_t ll_base[36]; uint32_t ml_base[53]; uint8_t ll_bits[36]; uint8_t ml_bits[53]; };
+__device__ static const seq_tabs SEQ_TABS = {
+	{ 0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,18,20,22,24,28,32,40,48,64,128,256,512,1024,2048,4096,8192,16384,32768,65536 },
+	{ 3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,32,33,34,35,37,39,41,43,47,51,59,67,83,99,131,259,515,1027,2051,4099,8195,16387,32771,65539 },
+	{ 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,2,2,3,3,4,6,7,8,9,10,11,12,13,14,15,16 },
+	{ 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,2,2,3,3,4,4,5,7,8,9,10,11,12,13,14,15,16 }
+};
 __device__ static const int16_t LL_DEF[36] = { 4,3,2,2,2,2,2,2,2,2,2,2,2,1,1,1,2,2,2,2,2,2,2,2,2,3,2,1,1,1,1,1,-1,-1,-1,-1 };
 __device__ static const int16_t ML_DEF[53] = { 1,4,3,2,2,2,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1,-1,-1 };
 __device__ static const int16_t OF_DEF[29] = { 1,1,1,1,1,1,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1 };
@@ -361,6 +374,7 @@ typedef struct {
 	fse_tab ll, of, ml; int have_ll, have_of, have_ml;
 	uint32_t rep[3];
 	uint8_t *lit;	/* 128 KiB + slack */
+	const seq_tabs *st;	/* length code tables: in LDS for the wave kernel */
 } zframe;
 
 /* one table of the sequences section; returns bytes consumed or -1 */
@@ -382,7 +396,43 @@ __device__ static int seq_table(fse_tab *t, int *have, int mode, const uint8_t *
 #define ZBLOCK_MAX (128u * 1024u)
 
 /* one compressed block; returns bytes produced or -1 */
-template <bool W> __device__ static int64_t zstd_block(zframe *f, const uint8_t *src, size_t len, uint8_t *dst, size_t dst_pos, size_t dst_cap)
+/* sequence decoder state: bit window, the three FSE states, the repeat offsets (registers, not the frame struct) */
+template <class R> struct seqdec { R rb; int64_t pos; uint32_t sl, so, sm, r0, r1, r2; };
+__device__ __forceinline__ static uint32_t fse_word(const fse_tab *t, uint32_t s) { uint32_t v; __builtin_memcpy(&v, &t->e[s], 4); return v; }	/* sym | nbits << 8 | base << 16 */
+
+/* next sequence (RFC 8878 3.1.1.3.2.1.1): values, repeat-offset rule, state update unless it is the block's last */
+template <class R> __device__ __forceinline__ static int seq_next(const zframe *f, seqdec<R> &d, bool last, uint32_t &ll, uint32_t &ml, uint32_t &offset)
+{
+	const uint32_t wo = fse_word(&f->of, d.so), wm = fse_word(&f->ml, d.sm), wl = fse_word(&f->ll, d.sl);
+	const uint32_t oc = wo & 0xFF, mc = wm & 0xFF, lc = wl & 0xFF;
+	if (oc > 31 || mc > 52 || lc > 35) return -1;
+	const uint32_t ov = (oc ? ((1u << oc) + bits_read(d.rb, &d.pos, oc)) : 1u);
+	ml = f->st->ml_base[mc] + bits_read(d.rb, &d.pos, f->st->ml_bits[mc]);
+	ll = f->st->ll_base[lc] + bits_read(d.rb, &d.pos, f->st->ll_bits[lc]);
+	if (d.pos < 0) return -1;
+	if (ov > 3) {
+		offset = ov - 3;
+		d.r2 = d.r1; d.r1 = d.r0; d.r0 = offset;
+	} else {
+		const uint32_t idx = ov - 1 + (ll == 0 ? 1u : 0u);	/* 0..3 */
+		if (idx == 0) offset = d.r0;
+		else {
+			offset = idx == 3 ? d.r0 - 1 : (idx == 1 ? d.r1 : d.r2);
+			if (offset == 0) return -1;
+			if (idx != 1) d.r2 = d.r1;
+			d.r1 = d.r0; d.r0 = offset;
+		}
+	}
+	if (!last) {
+		d.sl = (wl >> 16) + bits_read(d.rb, &d.pos, (wl >> 8) & 0xFF);
+		d.sm = (wm >> 16) + bits_read(d.rb, &d.pos, (wm >> 8) & 0xFF);
+		d.so = (wo >> 16) + bits_read(d.rb, &d.pos, (wo >> 8) & 0xFF);
+		if (d.pos < 0) return -1;
+	}
+	return 0;
+}
+
+template <bool W> __device__ __forceinline__ static int64_t zstd_block(zframe *f, const uint8_t *src, size_t len, uint8_t *dst, size_t dst_pos, size_t dst_cap)
 {
 	if (len < 1) return -1;	/* (libzstd: a compressed block needs at least a literals header) */
 	/* ---- literals section ---- */
@@ -475,52 +525,106 @@ template <bool W> __device__ static int64_t zstd_block(zframe *f, const uint8_t 
 		c = seq_table(&f->ll, &f->have_ll, modes >> 6, p, left, 9, 35, LL_DEF, 36, 6); if (c < 0) return -1; p += c; left -= (size_t)c;
 		c = seq_table(&f->of, &f->have_of, (modes >> 4) & 3, p, left, 8, 31, OF_DEF, 29, 5); if (c < 0) return -1; p += c; left -= (size_t)c;
 		c = seq_table(&f->ml, &f->have_ml, (modes >> 2) & 3, p, left, 9, 52, ML_DEF, 53, 6); if (c < 0) return -1; p += c; left -= (size_t)c;
-		int64_t pos = rev_init(p, left);
-		if (pos < 0) return -1;
-		rbits rb;
-		rb_init(rb, p, left);
-		uint32_t sl = rb_read(rb, &pos, (unsigned)f->ll.al);
-		uint32_t so = rb_read(rb, &pos, (unsigned)f->of.al);
-		uint32_t sm = rb_read(rb, &pos, (unsigned)f->ml.al);
-		if (pos < 0) return -1;
-		for (size_t i = 0; i < nseq; i++) {
-			const int oc = f->of.e[so].sym, mc = f->ml.e[sm].sym, lc = f->ll.e[sl].sym;
-			if (oc > 31 || mc > 52 || lc > 35) return -1;
-			const uint32_t ov = (oc ? ((1u << oc) + rb_read(rb, &pos, (unsigned)oc)) : 1u);
-			const uint32_t ml = ML_BASE[mc] + rb_read(rb, &pos, ML_BITS[mc]);
-			const uint32_t ll = LL_BASE[lc] + rb_read(rb, &pos, LL_BITS[lc]);
-			if (pos < 0) return -1;
-			uint32_t offset;
-			if (ov > 3) {
-				offset = ov - 3;
-				f->rep[2] = f->rep[1]; f->rep[1] = f->rep[0]; f->rep[0] = offset;
-			} else {
-				uint32_t idx = ov - 1 + (ll == 0 ? 1u : 0u);	/* 0..3 */
-				if (idx == 0) offset = f->rep[0];
-				else {
-					offset = idx == 3 ? f->rep[0] - 1 : f->rep[idx];
-					if (offset == 0) return -1;
-					if (idx != 1) f->rep[2] = f->rep[1];
-					f->rep[1] = f->rep[0]; f->rep[0] = offset;
+		seqdec<rbits> sd;
+		sd.pos = rev_init(p, left);
+		if (sd.pos < 0) return -1;
+		bits_init(sd.rb, p, left);
+		sd.sl = bits_read(sd.rb, &sd.pos, (unsigned)f->ll.al);
+		sd.so = bits_read(sd.rb, &sd.pos, (unsigned)f->of.al);
+		sd.sm = bits_read(sd.rb, &sd.pos, (unsigned)f->ml.al);
+		if (sd.pos < 0) return -1;
+		sd.r0 = f->rep[0]; sd.r1 = f->rep[1]; sd.r2 = f->rep[2];
+		if constexpr (!W) {
+			for (size_t i = 0; i < nseq; i++) {
+				uint32_t ll, ml, offset;
+				if (seq_next(f, sd, i + 1 == nseq, ll, ml, offset) < 0) return -1;
+				if (ll > regen - lit_pos) return -1;
+				if (out - dst_pos + ll + ml > ZBLOCK_MAX) return -1;
+				if (out + ll + ml > dst_cap) return -2;
+				dev_copy(dst + out, f->lit + lit_pos, ll); out += ll; lit_pos += ll;
+				if (offset > out) return -1;
+				t_match<false>(dst, out, offset, ml);
+				out += ml;
+			}
+		} else {
+			/* 64 sequences at a time: decoded by the whole wave (uniform), then executed one lane per sequence */
+			const uint32_t lane = __lane_id();
+			for (size_t base = 0; base < nseq; base += 64) {
+				const uint32_t cnt = nseq - base < 64 ? (uint32_t)(nseq - base) : 64u;
+				uint32_t my_ll = 0, my_ml = 0, my_off = 1;
+				size_t my_out = out, my_lit = 0;
+				for (uint32_t j = 0; j < cnt; j++) {
+					uint32_t ll, ml, offset;
+					if (seq_next(f, sd, base + j + 1 == nseq, ll, ml, offset) < 0) return -1;
+					if (ll > regen - lit_pos) return -1;
+					if (out - dst_pos + ll + ml > ZBLOCK_MAX) return -1;
+					if (out + ll + ml > dst_cap) return -2;
+					if (offset > out + ll) return -1;
+					if (lane == j) { my_ll = ll; my_ml = ml; my_off = offset; my_out = out; my_lit = lit_pos; }
+					out += (size_t)ll + ml; lit_pos += ll;
+				}
+				const bool have = lane < cnt;
+				/* literal runs: every lane its own */
+				{
+					const uint8_t *ls = f->lit + my_lit;
+					uint8_t *ld = dst + my_out;
+					uint32_t i = 0;
+					for (; i + 8 <= my_ll; i += 8) { uint64_t v; __builtin_memcpy(&v, ls + i, 8); __builtin_memcpy(ld + i, &v, 8); }
+					for (; i < my_ll; i++) ld[i] = ls[i];
+				}
+				wave_fence();	/* the literals of the group and everything in front of it are in place */
+				/* matches: a source that reaches into the group waits for the lanes whose sequences it touches */
+				const size_t g0 = (size_t)__shfl((int)(uint32_t)my_out, 0, 64) | ((size_t)__shfl((int)(uint32_t)((uint64_t)my_out >> 32), 0, 64) << 32);
+				const size_t mdst = my_out + my_ll;
+				const size_t s0 = mdst - my_off;
+				const uint32_t span = my_ml < my_off ? my_ml : my_off;
+				bool pendm = have && my_ml != 0;
+				uint64_t depmask = 0;
+				{
+					/* ends of the group's sequences relative to its first byte (increasing over the lanes) */
+					const uint32_t end = have ? (uint32_t)(mdst + my_ml - g0) : 0xFFFFFFFFu;
+					const bool inside = pendm && s0 + span > g0;
+					const uint32_t rlo = s0 > g0 ? (uint32_t)(s0 - g0) : 0u;
+					const uint32_t rhi = inside ? (uint32_t)(s0 + span - 1 - g0) : 0u;
+					uint32_t jlo = 0, jhi = 0;
+#pragma unroll
+					for (uint32_t bit = 32; bit; bit >>= 1) {
+						const uint32_t e_lo = (uint32_t)__shfl((int)end, (int)(jlo + bit - 1u), 64);
+						if (e_lo <= rlo) jlo += bit;
+						const uint32_t e_hi = (uint32_t)__shfl((int)end, (int)(jhi + bit - 1u), 64);
+						if (e_hi <= rhi) jhi += bit;
+					}
+					if (inside && lane != 0) {
+						const uint32_t hi = jhi < lane ? jhi : lane - 1u;	/* own literals are in place */
+						if (jlo <= hi) {
+							const uint64_t upto = hi >= 63u ? ~0ull : ((1ull << (hi + 1u)) - 1ull);
+							depmask = upto & ~((1ull << jlo) - 1ull);
+						}
+					}
+				}
+				for (;;) {
+					const uint64_t pending = __ballot(pendm);
+					if (pending == 0)
+						break;
+					if (pendm && (depmask & pending) == 0) {
+						const uint8_t *ms = dst + s0;
+						uint8_t *md = dst + mdst;
+						if (my_off >= my_ml) {
+							uint32_t i = 0;
+							for (; i + 8 <= my_ml; i += 8) { uint64_t v; __builtin_memcpy(&v, ms + i, 8); __builtin_memcpy(md + i, &v, 8); }
+							for (; i < my_ml; i++) md[i] = ms[i];
+						} else {
+							uint32_t m = 0;	/* i mod offset, carried */
+							for (uint32_t i = 0; i < my_ml; i++) { md[i] = ms[m]; m = m + 1 == my_off ? 0 : m + 1; }
+						}
+						pendm = false;
+					}
+					wave_fence();
 				}
 			}
-			if (i + 1 < nseq) {
-				sl = f->ll.e[sl].base + rb_read(rb, &pos, f->ll.e[sl].nbits);
-				sm = f->ml.e[sm].base + rb_read(rb, &pos, f->ml.e[sm].nbits);
-				so = f->of.e[so].base + rb_read(rb, &pos, f->of.e[so].nbits);
-				if (pos < 0) return -1;
-			}
-			/* execute */
-			if (ll > regen - lit_pos) return -1;
-			if (out - dst_pos + ll + ml > ZBLOCK_MAX) return -1;
-			if (out + ll + ml > dst_cap) return -2;
-			t_copy<W>(dst + out, f->lit + lit_pos, ll); out += ll; lit_pos += ll;
-			if (W) wave_fence();	/* this sequence's literals and everything before them are in place */
-			if (offset > out) return -1;
-			t_match<W>(dst, out, offset, ml);
-			out += ml;
 		}
-		if (pos != 0) return -1;	/* (libzstd 1.5 checks the exact end too; 1.4.8 does not) */
+		f->rep[0] = sd.r0; f->rep[1] = sd.r1; f->rep[2] = sd.r2;
+		if (sd.pos != 0) return -1;	/* (libzstd 1.5 checks the exact end too; 1.4.8 does not) */
 	} else if (left != 0) return -1;
 	const size_t rest = regen - lit_pos;
 	if (out - dst_pos + rest > ZBLOCK_MAX) return -1;
@@ -531,7 +635,7 @@ template <bool W> __device__ static int64_t zstd_block(zframe *f, const uint8_t 
 
 /* One frame at src (zstd or skippable).  *consumed = its compressed length.  Returns decoded bytes appended at
  * dst + dst_pos, or -1 format error, -2 dst too small, -3 truncated input. */
-template <bool W> __device__ static int64_t zstd_frame(const uint8_t *src, size_t len, uint8_t *dst, size_t dst_pos, size_t dst_cap, size_t *consumed, zframe *fp, uint8_t *litbuf, uint32_t options)
+template <bool W> __device__ __forceinline__ static int64_t zstd_frame(const uint8_t *src, size_t len, uint8_t *dst, size_t dst_pos, size_t dst_cap, size_t *consumed, zframe *fp, uint8_t *litbuf, uint32_t options)
 {
 	if (len < 4) return -3;
 	const uint32_t magic = rd32(src);
@@ -625,6 +729,7 @@ __global__ __launch_bounds__(64) void zstd_frames_kernel(const uint8_t *__restri
 		return;
 	zframe *fp = (zframe *)(ws + (size_t)w * ZSTD_WS_STRIDE);
 	uint8_t *lit = (uint8_t *)fp + 12288;
+	fp->st = &SEQ_TABS;
 	for (uint32_t i = w; i < n; i += lanes) {
 		const la_zstd_frame fr = frames[i];
 		la_zstd_result r;
@@ -653,6 +758,11 @@ __global__ __launch_bounds__(64) void zstd_frames_wave_kernel(const uint8_t *__r
     uint8_t *ws, uint32_t waves, uint32_t options)
 {
 	__shared__ zframe sf;
+	__shared__ seq_tabs s_tabs;
+	for (uint32_t i = threadIdx.x; i < sizeof(seq_tabs) / 4; i += 64)
+		((uint32_t *)&s_tabs)[i] = ((const uint32_t *)&SEQ_TABS)[i];
+	sf.st = &s_tabs;
+	__syncthreads();
 	const uint32_t w = blockIdx.x;
 	uint8_t *lit = ws + (size_t)w * ZSTD_WAVE_WS_STRIDE;
 	for (uint32_t i = w; i < n; i += waves) {
