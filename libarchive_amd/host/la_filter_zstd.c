@@ -179,6 +179,16 @@ static int zstd_next_window(struct archive_read_filter *self, struct zstd_privat
 	st->n = ir.n_frames;
 	st->next = 0;
 	st->end_kind = ir.end_kind;
+	if (st->out_budget && ir.dst_bytes > st->out_budget && ir.dst_bytes > ((uint64_t)4 << 30)) {
+		/* ONE frame whose blocks may decode to more than the window's budget (the walker stops adding frames at the
+		 * budget, so this is a single frame: e.g. terabytes of one byte as RLE blocks).  The reference streams such a
+		 * frame 128 KiB at a time; this data plane decodes whole frames into HBM and refuses it by name. */
+		archive_set_error(&self->archive->archive, ARCHIVE_ERRNO_MISC,
+		    "zstd frame too large for the GPU data plane (its blocks may decode to %llu bytes; LA_GPU_OUT_BUDGET_MIB)",
+		    (unsigned long long)ir.dst_bytes);
+		st->finished = 1;
+		return ARCHIVE_FATAL;
+	}
 	if (st->n) {
 		const size_t tab = sizeof(la_zstd_frame) * st->n, rtab = sizeof(la_zstd_result) * st->n;
 		if (grow_dev(st, &st->d_src, &st->d_src_cap, (size_t)ir.consumed + 64) != LA_OK) return gpu_fail(self, st, "la_gpu_malloc");

@@ -69,7 +69,7 @@ static int zstd_frame_extent(const uint8_t *p, uint64_t len, uint64_t *flen, uin
 		if (type == 3 || bsize > 128u * 1024u) {	/* the device names the error; nothing behind it can be found */
 			*bad_block = 1;
 			*flen = q;
-			*bound = fcs_len ? fcs : sum;
+			*bound = (fcs_len && fcs < sum) ? fcs : sum;	/* (never the bare claim: it may be forged) */
 			return 1;
 		}
 		const uint64_t body = type == 1 ? 1 : bsize;

@@ -132,3 +132,17 @@ def test_zstd_garbage_behind_a_frame(gpu_ctx):
     d = b"x" * 1000
     res = la_api.cat(Z.zstd_compress(z, d, 3) + b"garbage!")
     assert la_api.as_reference_tuple(res) == (d, la_api.ARCHIVE_FATAL, "Zstd decompression failed: Unknown frame descriptor")
+
+
+def test_zstd_frame_whose_blocks_claim_more_than_the_window_budget(gpu_ctx):
+    """40 000 RLE blocks of 128 KiB (5 GiB of one byte in 160 KB of input): the reference streams it; this data plane
+    decodes whole frames into HBM and must refuse it by name instead of asking for the memory (found by the ASan fuzz)."""
+    hdr = (0xFD2FB528).to_bytes(4, "little") + bytes([0x00, 0x70])       # no content size, window descriptor
+    blocks = bytearray()
+    nb = 40000
+    for i in range(nb):
+        bh = (1 if i == nb - 1 else 0) | (1 << 1) | ((128 * 1024) << 3)      # last?, RLE, Block_Size
+        blocks += bh.to_bytes(3, "little") + b"z"
+    res = la_api.cat(hdr + bytes(blocks))
+    assert res.rc == la_api.ARCHIVE_FATAL
+    assert res.error.startswith("zstd frame too large for the GPU data plane"), res.error

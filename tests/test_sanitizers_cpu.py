@@ -112,6 +112,22 @@ for size in (0, 1, 65535, 65536, 1 << 20, (1 << 20) + 1, 3 * (1 << 20) + 12345):
         n += 1
     rc, err = W.write_lz4(data, (), None, cap=max(1, size // 2))
     n += 1
+# zstd filter and frame walker: mutated / truncated multi-frame streams (frame headers, block headers, skippable frames)
+import zstd_support as Z
+zz = Z.libzstd()
+if zz is not None:
+    parts = []
+    for i in range(40):
+        parts.append(Z.zstd_compress(zz, Z.gen(rnd, rnd.choice([0, 10, 3000, 140000]), rnd.randint(1, 4)), rnd.choice([1, 3, 19])))
+        if i % 7 == 3:
+            parts.append(Z.skippable(b"k" * i, i % 16))
+    zimg = b"".join(parts)
+    for m in mutations(zimg, 400):
+        la_api.cat(m, read_size=rnd.choice([None, 7, 1000])); n += 1
+    for pos in range(0, 40):
+        for v in (0, 1, 0x7f, 0x80, 0xff):
+            m = bytearray(zimg); m[pos] = v
+            la_api.cat(bytes(m)); n += 1
 # ZIP reader: mutated archives (directory records, local headers, bodies, end record) must fail cleanly
 from test_gpu_zip import _make_zip
 import zipfile
