@@ -22,10 +22,11 @@
  *   zstd_frames_kernel (LA_ZSTD_OPT_LANE_KERNEL)  the first form, one LANE per frame with its tables in an HBM
  *       workspace slot: same results, kept as a cross-check.
  * Measured (tools/measure_zstd.py, profiles/r02_zstd.txt): 16 384 frames of 64 KiB at level 3 decode at 18 GiB/s
- * resident in HBM (lane form: 6.1) against 2.8 GiB/s for libzstd on one host core.  The kernel is bound by
- * instruction issue in the uniform part: 675 k VALU + 480 k SALU instructions per 64 KiB frame (about 350 per
- * sequence: 64-bit positions, six checked bit reads), 87 % of a frame's cycles in the 64-sequence decode loop.  Next:
- * 32-bit block-relative positions and a shift-register bit reader, then one lane per FSE stream of different blocks.
+ * resident in HBM (lane form: 6.1) against 2.9 GiB/s for libzstd on one host core.  87 % of a frame's cycles go to the
+ * uniform 64-sequence decode loop: about 350 instructions per sequence, but ONE dependency chain per wave (state -> LDS
+ * table word -> length table -> bit read -> next state); fewer branches changed nothing and moving the chain to the scalar
+ * unit (v_readfirstlane, ZSTD_SCALAR) made it slower, and the 10.8 KiB of LDS tables hold a CU to 14 waves.  Next: two or
+ * more frames interleaved per wave (independent chains), smaller tables for occupancy.
  */
 #include "la_dev.h"
 
