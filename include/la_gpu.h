@@ -181,6 +181,8 @@ typedef struct la_batch_summary {
 #define LA_LZ4_OPT_EXPAND_QUEUE 8u	/* second implementation of the LDS-window expand step (la_lz4_fastq.hip: byte-validity
 					 * bitmap, shared ready queue, aligned LDS copies); same results, kept as a cross-check
 					 * and for blocks of long overlapping matches */
+#define LA_LZ4_OPT_EXPAND_RING 64u	/* fourth implementation (la_lz4_wide.hip, lz4_expand_ring_kernel: one wave per block, the last 8 KiB of
+					 * output in an LDS ring, one fence per 64 sequences); same results */
 #define LA_LZ4_OPT_EXPAND_WIDE 32u	/* third implementation of the expand step (la_lz4_wide.hip: one wave per block, one lane per
 					 * sequence, the output window in the decoded slab itself instead of LDS); same results */
 

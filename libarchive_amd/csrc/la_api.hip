@@ -342,7 +342,8 @@ int la_gpu_lz4_decode(la_gpu_ctx *c, const la_lz4_batch *bt)
 	const bool fast = !(bt->options & LA_LZ4_OPT_GENERAL_ONLY);
 	const bool verify = !(bt->options & LA_LZ4_OPT_NO_VERIFY);
 	const bool queue = (bt->options & LA_LZ4_OPT_EXPAND_QUEUE) != 0;
-	const bool wide = (bt->options & LA_LZ4_OPT_EXPAND_WIDE) != 0;
+	const bool ring = (bt->options & LA_LZ4_OPT_EXPAND_RING) != 0;
+	const bool wide = ring || (bt->options & LA_LZ4_OPT_EXPAND_WIDE) != 0;
 	lz4_ws w;
 	lz4_ws_layout(&w, NULL, bt->n_blocks, bt->src_bytes, fast);
 	if (w.total > c->ws_bytes) {
@@ -421,7 +422,7 @@ int la_gpu_lz4_decode(la_gpu_ctx *c, const la_lz4_batch *bt)
 		const uint32_t first = (uint32_t)((uint64_t)n * i / nsl), last = (uint32_t)((uint64_t)n * (i + 1) / nsl);
 		if (fast && wide) {
 			h = prof_open(c, "lz4_expand", sx);
-			la_launch_lz4_expand_wide(sx, bt->d_src, bt->src_bytes, bt->d_blocks + first, last - first, bt->d_dst,
+			(ring ? la_launch_lz4_expand_ring : la_launch_lz4_expand_wide)(sx, bt->d_src, bt->src_bytes, bt->d_blocks + first, last - first, bt->d_dst,
 			    bt->dst_cap, bt->d_dst_off + first, bt->d_out_len + first, bt->d_block_status + first,
 			    w.nseq + first, w.table, w.table_off + first, LA_LZ4_LONG_SEQ_BYTES);
 			prof_close(c, h, sx);

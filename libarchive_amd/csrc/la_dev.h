@@ -395,6 +395,11 @@ uint64_t la_zstd_workspace_bytes(uint32_t n_frames);
 void la_launch_zstd_frames(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes, const la_zstd_frame *d_frames, uint32_t n,
     uint8_t *d_dst, uint64_t dst_cap, la_zstd_result *d_results, uint8_t *ws, uint32_t options);
 
+void la_launch_lz4_expand_ring(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
+    const la_lz4_block *d_blocks, uint32_t n, uint8_t *d_dst, uint64_t dst_cap,
+    const uint64_t *d_dst_off, const uint32_t *d_out_len, uint32_t *d_status,
+    const uint32_t *d_nseq, const la_lz4_seq *d_table, const uint64_t *d_table_off, uint32_t long_thr);
+
 /* la_lz4_comp.hip */
 void la_launch_lz4_compress(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes, uint32_t block_size,
     uint32_t bpf, uint32_t flags, uint8_t *d_out, uint64_t out_cap, uint64_t *d_out_bytes, uint8_t *ws);

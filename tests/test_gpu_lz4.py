@@ -25,7 +25,7 @@ def gpu_decode(ctx, image, options=None):
     res = []
     for opt in ((0, N.LA_LZ4_OPT_GENERAL_ONLY, N.LA_LZ4_OPT_PARSE_V1,
                  N.LA_LZ4_OPT_PARSE_V1 | N.LA_LZ4_OPT_GENERAL_ONLY,
-                 N.LA_LZ4_OPT_EXPAND_QUEUE, N.LA_LZ4_OPT_EXPAND_WIDE) if options is None else (options,)):
+                 N.LA_LZ4_OPT_EXPAND_QUEUE, N.LA_LZ4_OPT_EXPAND_WIDE, N.LA_LZ4_OPT_EXPAND_RING) if options is None else (options,)):
         out, rc, msg, plan = decode_image(ctx, image, options=opt)
         res.append((out.tobytes(), rc, msg))
     assert all(r == res[0] for r in res), "kernel variants disagree (expand fast/general/queue/wide x parse staged/v1)"
