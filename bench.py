@@ -234,6 +234,70 @@ def _gz_make_member(args):
     return hdr + body + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data))
 
 
+
+def zstd_object(ctx, torch):
+    """SURVEY 8f-3 in the same driver-run command: 16 384 zstd frames of 64 KiB (libzstd level 3 output of synthetic
+    text-like data, 64 distinct frames tiled) through la_gpu_zstd_decode, inputs resident in HBM, every frame's status
+    and the first 64 frames' bytes checked; libzstd on one host core beside it.  Carried as `tertiary`."""
+    import ctypes
+    import random
+    import zstd_support as Z
+    from libarchive_amd import zstd as LZ
+    z = Z.libzstd()
+    if z is None:
+        return {"skipped": "no libzstd.so.1 in this image to make the synthetic stream"}
+    nfr, kib, lvl = 16384, 64, 3
+    rnd = random.Random(1)
+    uniq = []
+    for i in range(64):
+        d = Z.gen(rnd, kib * 1024, 2 if i % 2 else 4)
+        uniq.append((d, Z.zstd_compress(z, d, lvl)))
+    img = b"".join(uniq[i % 64][1] for i in range(nfr))
+    plain_len = nfr * kib * 1024
+    # CPU: the library the reference's filter calls, one core, the 64 distinct frames in one ZSTD_decompress call
+    sample = b"".join(u[1] for u in uniq)
+    buf = ctypes.create_string_buffer(64 * kib * 1024 + 64)
+    t0 = time.time()
+    reps = 0
+    while time.time() - t0 < 5.0:
+        z.ZSTD_decompress(buf, len(buf), sample, len(sample))
+        reps += 1
+    cpu_s = time.time() - t0
+    cpu = reps * 64 * kib * 1024 / cpu_s / 2**20
+    frames, end_kind, consumed, dst_bytes = LZ.index_image(img)
+    assert len(frames) == nfr and consumed == len(img)
+    d_src = torch.from_numpy(np.frombuffer(img, dtype=np.uint8).copy()).cuda()
+    plan = LZ.ZstdDevicePlan(ctx, d_src, frames, dst_bytes)
+    plan.run()
+    res = plan.results()
+    ok = bool((res["status"] == 0).all()) and int(res["out_len"].sum()) == plain_len
+    head = plan.d_dst[:64 * kib * 1024].cpu().numpy().tobytes()
+    ok = ok and head == b"".join(u[0] for u in uniq)
+    for _ in range(2):
+        plan.run()
+    ctx.sync()
+    K = 5
+    t0 = time.time()
+    for _ in range(K):
+        plan.run()
+    ctx.sync()
+    dt = (time.time() - t0) / K
+    achieved = (len(img) + plain_len) / dt / 1e9
+    return {
+        "metric": "decompressed MiB/s (whole node), zstd read filter data plane, bit-exact",
+        "value": round(plain_len / dt / 2**20, 1), "unit": "MiB/s", "n_gpus": 1, "steps": K, "warmup": 3,
+        "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "%d zstd frames of %d KiB decoded (libzstd %d level %d output, 64 distinct frames tiled), "
+                               "one wave per frame, inputs resident in HBM" % (nfr, kib, z.ZSTD_versionNumber(), lvl),
+                   "compressed_bytes": len(img), "decoded_bytes": plain_len},
+        "bit_exact": ok,
+        "roofline": {"bound": "hbm", "kernel": "zstd_frames_wave_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "algorithmic_bytes": len(img) + plain_len},
+        "cpu_baseline": {"value": round(cpu, 1), "unit": "MiB/s", "cores": 1, "kind": "libzstd",
+                         "sample": "%d x %d MiB decoded, ZSTD_decompress over the 64 distinct frames, %.1f s" % (reps, 64 * kib // 1024, cpu_s)},
+    }
+
 def main_gzip(args, as_secondary=False):
     """configs[2] shape: concatenated gzip members of 64 KiB with a BGZF-style size subfield,
     CRC32 + ISIZE verified on the device.  `--workload gzip` prints it as its own line; the default run
@@ -561,6 +625,9 @@ def main():
             torch.cuda.empty_cache()
             line["secondary"] = main_gzip(args, as_secondary=True)
             ok_all = ok_all and bool(line["secondary"]["bit_exact"])
+            torch.cuda.empty_cache()
+            line["tertiary"] = zstd_object(ctx, torch)
+            ok_all = ok_all and bool(line["tertiary"].get("bit_exact", True))
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
