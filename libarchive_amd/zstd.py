@@ -20,14 +20,16 @@ class _ZstdBatchC(C.Structure):
                 ("options", C.c_uint32), ("d_dst", C.c_void_p), ("dst_cap", C.c_uint64), ("d_results", C.c_void_p)]
 
 
-def index_image(image, at_eof=True, cap=1 << 20):
+def index_image(image, at_eof=True, cap=1 << 20, out_budget=0, full=False):
     """(frames ndarray, end_kind, consumed, dst_bytes) of a host image (bytes / uint8 ndarray)."""
     lib = N.host_lib()
     buf = np.frombuffer(image, dtype=np.uint8) if not isinstance(image, np.ndarray) else image
     frames = np.zeros(cap, dtype=ZSTD_FRAME_DTYPE)
     res = _IndexResultC()
     lib.la_zstd_index_build.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_uint64, C.c_void_p, C.c_uint32, C.POINTER(_IndexResultC)]
-    lib.la_zstd_index_build(buf.ctypes.data, buf.size, 1 if at_eof else 0, 0, frames.ctypes.data, cap, C.byref(res))
+    lib.la_zstd_index_build(buf.ctypes.data, buf.size, 1 if at_eof else 0, int(out_budget), frames.ctypes.data, cap, C.byref(res))
+    if full:
+        return frames[:res.n_frames].copy(), res
     return frames[:res.n_frames].copy(), res.end_kind, res.consumed, res.dst_bytes
 
 
