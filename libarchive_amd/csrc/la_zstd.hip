@@ -21,7 +21,7 @@
  *       positions; the scheme of la_lz4_wide.hip's in-order path).
  *   zstd_frames_kernel (LA_ZSTD_OPT_LANE_KERNEL)  the first form, one LANE per frame with its tables in an HBM
  *       workspace slot: same results, kept as a cross-check.
- * Measured (tools/measure_zstd.py, profiles/r02_zstd.txt): 16 384 frames of 64 KiB at level 3 decode at 18 GiB/s
+ * Measured (tools/measure_zstd.py, profiles/r02_zstd.txt): 16 384 frames of 64 KiB at level 3 decode at 20 GiB/s
  * resident in HBM (lane form: 6.1) against 2.9 GiB/s for libzstd on one host core.  87 % of a frame's cycles go to the
  * uniform 64-sequence decode loop: about 350 instructions per sequence, but ONE dependency chain per wave (state -> LDS
  * table word -> length table -> bit read -> next state); fewer branches changed nothing and moving the chain to the scalar
@@ -428,8 +428,15 @@ template <bool U, class R> __device__ __forceinline__ static int seq_next(const 
 	bool bad = (oc > 31) | (mc > 52) | (lc > 35);
 	oc = oc > 31 ? 31 : oc; mc = mc > 52 ? 52 : mc; lc = lc > 35 ? 35 : lc;
 	const uint32_t ov = (1u << oc) + bits_read<U>(d.rb, &d.pos, oc);	/* (code 0: value 1, no bits) */
-	ml = uni<U>(f->tabs.ml_base[mc]) + bits_read<U>(d.rb, &d.pos, uni<U>(f->tabs.ml_bits[mc]));
-	ll = uni<U>(f->tabs.ll_base[lc]) + bits_read<U>(d.rb, &d.pos, uni<U>(f->tabs.ll_bits[lc]));
+	/* codes without extra bits (match lengths 3..34, literal lengths 0..15: the common case) need no table: the second
+	 * LDS trip of the chain is skipped for them.  The extra bits of the match length and of the literal length come
+	 * out of ONE read (at most 16 + 16 bits; the match length's were written last, so they are the high part). */
+	uint32_t mb = mc + 3u, lb = lc, mbits = 0, lbits = 0;
+	if (mc >= 32u) { mb = uni<U>(f->tabs.ml_base[mc]); mbits = uni<U>(f->tabs.ml_bits[mc]); }
+	if (lc >= 16u) { lb = uni<U>(f->tabs.ll_base[lc]); lbits = uni<U>(f->tabs.ll_bits[lc]); }
+	const uint32_t ev = bits_read<U>(d.rb, &d.pos, mbits + lbits);
+	ml = mb + (ev >> lbits);
+	ll = lb + (ev & ((1u << lbits) - 1u));
 	bad |= d.pos < 0;
 	/* repeat offsets (RFC 8878 3.1.1.5) with selects */
 	const bool rep = ov <= 3;
@@ -443,9 +450,12 @@ template <bool U, class R> __device__ __forceinline__ static int seq_next(const 
 	d.r1 = shift ? d.r0 : d.r1;
 	d.r0 = shift ? offset : d.r0;
 	if (!last) {
-		d.sl = (wl >> 16) + bits_read<U>(d.rb, &d.pos, (wl >> 8) & 0xFF);
-		d.sm = (wm >> 16) + bits_read<U>(d.rb, &d.pos, (wm >> 8) & 0xFF);
-		d.so = (wo >> 16) + bits_read<U>(d.rb, &d.pos, (wo >> 8) & 0xFF);
+		/* the three state updates out of ONE read (at most 9 + 9 + 8 bits; order in the stream: LL, ML, OF) */
+		const uint32_t nl = (wl >> 8) & 0xFF, nm = (wm >> 8) & 0xFF, no = (wo >> 8) & 0xFF;
+		const uint32_t sv = bits_read<U>(d.rb, &d.pos, nl + nm + no);
+		d.sl = (wl >> 16) + (sv >> (nm + no));
+		d.sm = (wm >> 16) + ((sv >> no) & ((1u << nm) - 1u));
+		d.so = (wo >> 16) + (sv & ((1u << no) - 1u));
 		bad |= d.pos < 0;
 	}
 	return bad ? -1 : 0;
@@ -577,6 +587,14 @@ template <bool W> __device__ __forceinline__ static int64_t zstd_block(zframe *f
 				size_t my_out = out, my_lit = 0;
 				for (uint32_t j = 0; j < cnt; j++) {
 					uint32_t ll, ml, offset;
+					if (ZSTD_SCALAR) {	/* loop-carried state back into scalar registers: the compiler cannot prove it uniform across the back edge */
+						j = uni<ZSTD_SCALAR>(j);
+						sd.pos = unis<ZSTD_SCALAR>(sd.pos); sd.rb.lo = unis<ZSTD_SCALAR>(sd.rb.lo); sd.rb.win = uni64<ZSTD_SCALAR>(sd.rb.win);
+						sd.rb.len = uni<ZSTD_SCALAR>(sd.rb.len); sd.rb.src = (const uint8_t *)uni64<ZSTD_SCALAR>((uint64_t)sd.rb.src);
+						sd.sl = uni<ZSTD_SCALAR>(sd.sl); sd.sm = uni<ZSTD_SCALAR>(sd.sm); sd.so = uni<ZSTD_SCALAR>(sd.so);
+						sd.r0 = uni<ZSTD_SCALAR>(sd.r0); sd.r1 = uni<ZSTD_SCALAR>(sd.r1); sd.r2 = uni<ZSTD_SCALAR>(sd.r2);
+						out = (size_t)uni64<ZSTD_SCALAR>(out); lit_pos = (size_t)uni64<ZSTD_SCALAR>(lit_pos);
+					}
 					if (seq_next<ZSTD_SCALAR>(f, sd, base + j + 1 == nseq, ll, ml, offset) < 0) return -1;
 					if (ll > regen - lit_pos) return -1;
 					if (out - dst_pos + ll + ml > ZBLOCK_MAX) return -1;
