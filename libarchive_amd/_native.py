@@ -107,6 +107,15 @@ def gpu_lib():
             raise NativeLibraryMissing(
                 "%s not found: build it with `make -C libarchive_amd/csrc` (hipcc, gfx950); "
                 "there is no CPU fallback" % GPU_LIB_PATH)
+        # This harness shares device buffers with PyTorch, and the PyTorch wheel carries its own HIP runtime: it has to
+        # be the one already loaded when libla_gpu.so resolves libamdhip64, or the process ends up with two runtimes and
+        # la_gpu_open() sees no device (found with `python __graft_entry__.py smoke`, where build() loaded this library
+        # before smoke() imported torch).  A C caller (la_cat, the filters inside libarchive) links the system runtime
+        # and never meets torch.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(GPU_LIB_PATH)
         lib.la_gpu_abi_version.restype = C.c_int
         lib.la_gpu_device_count.restype = C.c_int
