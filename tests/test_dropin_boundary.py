@@ -56,7 +56,7 @@ def test_restated_structs_have_the_reference_layout(tmp_path):
     assert mine == ref
 
 
-@pytest.mark.parametrize("src", ["la_filter_lz4.c", "la_filter_gzip.c"])
+@pytest.mark.parametrize("src", ["la_filter_lz4.c", "la_filter_gzip.c", "la_filter_zstd.c"])
 def test_filters_compile_against_the_real_private_headers(src):
     cmd = ["gcc", "-fsyntax-only", "-Wall", "-Werror=implicit-function-declaration", "-DLA_IN_LIBARCHIVE",
            "-I" + ROOT + "/include", os.path.join(ROOT, "libarchive_amd", "host", src)] + REF_FLAGS
