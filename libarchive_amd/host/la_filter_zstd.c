@@ -20,6 +20,7 @@ struct zstd_private {
 	la_gpu_ctx *gpu;
 	size_t batch_bytes;		/* compressed bytes gathered per window */
 	uint64_t out_budget;		/* decoded bytes asked for per window */
+	size_t max_batch_bytes;		/* how far the stage may grow for ONE frame larger than a window */
 	/* stage: compressed bytes not decoded yet */
 	uint8_t *stage; size_t stage_len, stage_cap;
 	int upstream_eof;
@@ -82,6 +83,8 @@ static int zstd_reader_init(struct archive_read_filter *self)
 	st->batch_bytes = (size_t)(bm && atoi(bm) > 0 ? atoi(bm) : 256) << 20;
 	const char *ob = getenv("LA_GPU_OUT_BUDGET_MIB");
 	st->out_budget = (uint64_t)(ob && atoi(ob) > 0 ? atoi(ob) : 4096) << 20;
+	const char *bmx = getenv("LA_GPU_MAX_BATCH_MIB");
+	st->max_batch_bytes = (size_t)(bmx && atoi(bmx) > 0 ? atoi(bmx) : 2048) << 20;
 	int rc = la_gpu_open(dev ? atoi(dev) : 0, &st->gpu);
 	if (rc != LA_OK) {
 		archive_set_error(&self->archive->archive, ARCHIVE_ERRNO_MISC,
@@ -171,7 +174,18 @@ static int zstd_next_window(struct archive_read_filter *self, struct zstd_privat
 		}
 		la_zstd_index_build(st->stage, st->stage_len, st->upstream_eof, st->out_budget, st->frames, st->frames_cap, &ir);
 		if (ir.n_frames == 0 && ir.end_kind == LA_END_NEED_MORE && !ir.window_full && !st->upstream_eof) {
+			if (st->stage_len >= st->max_batch_bytes) {
+				/* ONE frame whose compressed bytes alone pass LA_GPU_MAX_BATCH_MIB: the whole frame would have to sit in
+				 * host memory and HBM; refused by name (the reference streams it) */
+				archive_set_error(&self->archive->archive, ARCHIVE_ERRNO_MISC,
+				    "zstd frame too large for the GPU data plane (more than %llu compressed bytes; LA_GPU_MAX_BATCH_MIB)",
+				    (unsigned long long)st->max_batch_bytes);
+				st->finished = 1;
+				return ARCHIVE_FATAL;
+			}
 			want = st->stage_len * 2 > want ? st->stage_len * 2 : want * 2;	/* one frame larger than the window: gather on */
+			if (want > st->max_batch_bytes)
+				want = st->max_batch_bytes;
 			continue;
 		}
 		break;

@@ -146,3 +146,20 @@ def test_zstd_frame_whose_blocks_claim_more_than_the_window_budget(gpu_ctx):
     res = la_api.cat(hdr + bytes(blocks))
     assert res.rc == la_api.ARCHIVE_FATAL
     assert res.error.startswith("zstd frame too large for the GPU data plane"), res.error
+
+
+def test_zstd_one_frame_larger_than_the_gather_limit(gpu_ctx, monkeypatch):
+    """a frame of 3 MiB of raw blocks with the gather limit at 1 MiB: refused by name, not gathered without bound;
+    the same frame passes with the default limit"""
+    hdr = (0xFD2FB528).to_bytes(4, "little") + bytes([0x00, 0x70])
+    body = bytearray()
+    nb = 24
+    for i in range(nb):
+        body += ((1 if i == nb - 1 else 0) | (0 << 1) | ((128 * 1024) << 3)).to_bytes(3, "little") + bytes([65 + i]) * (128 * 1024)
+    img = hdr + bytes(body)
+    want = b"".join(bytes([65 + i]) * (128 * 1024) for i in range(nb))
+    assert la_api.as_reference_tuple(la_api.cat(img, read_size=65536)) == (want, 0, "")
+    monkeypatch.setenv("LA_GPU_BATCH_MIB", "1")
+    monkeypatch.setenv("LA_GPU_MAX_BATCH_MIB", "1")
+    res = la_api.cat(img, read_size=65536)
+    assert res.rc == la_api.ARCHIVE_FATAL and res.error.startswith("zstd frame too large for the GPU data plane (more than"), res.error

@@ -71,6 +71,7 @@ from test_gpu_zstd import (  # noqa: E402,F401
     test_zstd_truncated_and_damaged_streams,
     test_zstd_garbage_behind_a_frame,
     test_zstd_frame_whose_blocks_claim_more_than_the_window_budget,
+    test_zstd_one_frame_larger_than_the_gather_limit,
 )
 
 from test_gpu_zip import (  # noqa: E402,F401
