@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LA_GPU_ABI_VERSION 2
+#define LA_GPU_ABI_VERSION 3
 
 typedef enum la_rc {
 	LA_OK            = 0,
@@ -178,13 +178,9 @@ typedef struct la_batch_summary {
 #define LA_LZ4_OPT_PARSE_V1     4u	/* first-generation parse: block checksums and token walk as two kernels
 					 * reading global memory per lane (kept as a cross-check of the staged one) */
 
-#define LA_LZ4_OPT_EXPAND_QUEUE 8u	/* second implementation of the LDS-window expand step (la_lz4_fastq.hip: byte-validity
-					 * bitmap, shared ready queue, aligned LDS copies); same results, kept as a cross-check
-					 * and for blocks of long overlapping matches */
-#define LA_LZ4_OPT_EXPAND_RING 64u	/* fourth implementation (la_lz4_wide.hip, lz4_expand_ring_kernel: one wave per block, the last 8 KiB of
-					 * output in an LDS ring, one fence per 64 sequences); same results */
-#define LA_LZ4_OPT_EXPAND_WIDE 32u	/* third implementation of the expand step (la_lz4_wide.hip: one wave per block, one lane per
-					 * sequence, the output window in the decoded slab itself instead of LDS); same results */
+#define LA_LZ4_OPT_EXPAND_POLL  8u	/* previous generation of the LDS-window expand step (la_lz4_fast.hip: one thread per
+					 * sequence, matches poll per-sequence done bits); same results, kept as the cross-check of
+					 * the in-order kernel (la_lz4_inorder.hip), which is the default since ABI 3 */
 
 typedef struct la_lz4_batch {
 	const uint8_t      *d_src;	/* compressed image (or batch window) in HBM */
@@ -254,6 +250,7 @@ typedef struct la_gz_batch {
 #define LA_GZ_OPT_LANE_KERNEL 4u	/* force the in-place lane-per-member kernel */
 #define LA_GZ_OPT_TWO_PHASE   8u	/* force entropy decode + LDS-window expand (the default from 8192 members up) */
 
+#define LA_GZ_OPT_EXPAND_POLL 32u	/* two-phase path: build the output with the previous-generation expand kernel (cross-check) */
 #define LA_GZ_OPT_RAW        16u	/* members are bare raw-deflate streams (ZIP entries, archive_read_support_format_zip.c:2536-2700):
 					 * no gzip trailer follows the body, nothing is compared; status, out_len, consumed and
 					 * the CRC32 of the produced bytes are reported */

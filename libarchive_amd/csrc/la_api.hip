@@ -341,9 +341,7 @@ int la_gpu_lz4_decode(la_gpu_ctx *c, const la_lz4_batch *bt)
 		return LA_ERR_ARG;
 	const bool fast = !(bt->options & LA_LZ4_OPT_GENERAL_ONLY);
 	const bool verify = !(bt->options & LA_LZ4_OPT_NO_VERIFY);
-	const bool queue = (bt->options & LA_LZ4_OPT_EXPAND_QUEUE) != 0;
-	const bool ring = (bt->options & LA_LZ4_OPT_EXPAND_RING) != 0;
-	const bool wide = ring || (bt->options & LA_LZ4_OPT_EXPAND_WIDE) != 0;
+	const bool poll = (bt->options & LA_LZ4_OPT_EXPAND_POLL) != 0;	/* previous-generation expand kernel (cross-check) */
 	lz4_ws w;
 	lz4_ws_layout(&w, NULL, bt->n_blocks, bt->src_bytes, fast);
 	if (w.total > c->ws_bytes) {
@@ -407,11 +405,12 @@ int la_gpu_lz4_decode(la_gpu_ctx *c, const la_lz4_batch *bt)
 	    fast ? 0xFFFFFFFEu : 0u,	/* the LDS-window kernel takes every eligible block that got a table ... */
 	    bt->hist_len, LA_LZ4_LONG_SEQ_BYTES);	/* ... except blocks of few long sequences (la_dev.h) */
 	prof_close(c, h, sx);
-	if (fast && !wide) {
-		/* eligible blocks with more sequences than one LDS segment: classified on the device,
-		 * shared out over a small grid (a no-op launch when there are none) */
+	if (fast && poll) {
+		/* eligible blocks with more sequences than one LDS segment of the polling kernel: classified on the
+		 * device, shared out over a small grid (a no-op launch when there are none).  The in-order kernel
+		 * takes blocks of any sequence count. */
 		h = prof_open(c, "lz4_expand_big", sx);
-		(queue ? la_launch_lz4_expand_queue_big : la_launch_lz4_expand_fast_big)(sx, bt->d_src, bt->src_bytes, bt->d_blocks, n, bt->d_dst, bt->dst_cap,
+		la_launch_lz4_expand_fast_big(sx, bt->d_src, bt->src_bytes, bt->d_blocks, n, bt->d_dst, bt->dst_cap,
 		    bt->d_dst_off, bt->d_out_len, bt->d_block_status, w.nseq, w.table, w.table_off, w.big, LA_LZ4_LONG_SEQ_BYTES);
 		prof_close(c, h, sx);
 	}
@@ -420,15 +419,9 @@ int la_gpu_lz4_decode(la_gpu_ctx *c, const la_lz4_batch *bt)
 		HIPCHK(c, hipMemsetAsync(bt->d_frame_status, 0, (size_t)bt->n_frames * sizeof(uint32_t), sx));
 	for (uint32_t i = 0; i < nsl; i++) {
 		const uint32_t first = (uint32_t)((uint64_t)n * i / nsl), last = (uint32_t)((uint64_t)n * (i + 1) / nsl);
-		if (fast && wide) {
+		if (fast) {
 			h = prof_open(c, "lz4_expand", sx);
-			(ring ? la_launch_lz4_expand_ring : la_launch_lz4_expand_wide)(sx, bt->d_src, bt->src_bytes, bt->d_blocks + first, last - first, bt->d_dst,
-			    bt->dst_cap, bt->d_dst_off + first, bt->d_out_len + first, bt->d_block_status + first,
-			    w.nseq + first, w.table, w.table_off + first, LA_LZ4_LONG_SEQ_BYTES);
-			prof_close(c, h, sx);
-		} else if (fast) {
-			h = prof_open(c, "lz4_expand", sx);
-			(queue ? la_launch_lz4_expand_queue : la_launch_lz4_expand_fast)(sx, bt->d_src, bt->src_bytes, bt->d_blocks + first, last - first, bt->d_dst,
+			(poll ? la_launch_lz4_expand_fast : la_launch_lz4_expand_inorder)(sx, bt->d_src, bt->src_bytes, bt->d_blocks + first, last - first, bt->d_dst,
 			    bt->dst_cap, bt->d_dst_off + first, bt->d_out_len + first, bt->d_block_status + first,
 			    w.nseq + first, w.table, w.table_off + first, LA_LZ4_LONG_SEQ_BYTES);
 			prof_close(c, h, sx);
@@ -546,11 +539,16 @@ int la_gpu_gzip_decode(la_gpu_ctx *c, const la_gz_batch *bt)
 		la_launch_inflate_symbols(s, bt->d_src, bt->src_bytes, bt->d_members, n, bt->dst_cap, bt->d_results, wsb, E);
 		prof_close(c, h, s);
 		h = prof_open(c, "inflate_expand", s);
-		la_launch_lz4_expand_fast(s, E.lit, (uint64_t)n * 65536u, E.blocks, n, bt->d_dst, bt->dst_cap,
-		    E.dst_off, E.out_len, E.xstatus, E.nseq, E.table, E.table_off, 0u);
-		/* members with more matches than one LDS segment holds */
-		la_launch_lz4_expand_fast_big(s, E.lit, (uint64_t)n * 65536u, E.blocks, n, bt->d_dst, bt->dst_cap,
-		    E.dst_off, E.out_len, E.xstatus, E.nseq, E.table, E.table_off, gz_big, 0u);
+		if (bt->options & LA_GZ_OPT_EXPAND_POLL) {
+			la_launch_lz4_expand_fast(s, E.lit, (uint64_t)n * 65536u, E.blocks, n, bt->d_dst, bt->dst_cap,
+			    E.dst_off, E.out_len, E.xstatus, E.nseq, E.table, E.table_off, 0u);
+			/* members with more matches than one LDS segment of the polling kernel holds */
+			la_launch_lz4_expand_fast_big(s, E.lit, (uint64_t)n * 65536u, E.blocks, n, bt->d_dst, bt->dst_cap,
+			    E.dst_off, E.out_len, E.xstatus, E.nseq, E.table, E.table_off, gz_big, 0u);
+		} else {
+			la_launch_lz4_expand_inorder(s, E.lit, (uint64_t)n * 65536u, E.blocks, n, bt->d_dst, bt->dst_cap,
+			    E.dst_off, E.out_len, E.xstatus, E.nseq, E.table, E.table_off, 0u);
+		}
 		prof_close(c, h, s);
 		/* members the LDS-window kernel cannot take: decoded in place */
 		h = prof_open(c, "inflate", s);

@@ -304,6 +304,35 @@ __device__ __forceinline__ uint32_t win_u32(src_window &W, const uint8_t *q, int
 	return __builtin_amdgcn_alignbyte(hi, lo, d & 3);
 }
 
+/* LDS accepts unaligned 2/4/8-byte accesses on gfx950 (the compiler emits
+ * ds_read_b64 / ds_write_b64 for these), so window copies move 8 bytes per
+ * instruction at any byte address. */
+__device__ __forceinline__ uint64_t lds_ld8(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+__device__ __forceinline__ void lds_st8(uint8_t *p, uint64_t v) { __builtin_memcpy(p, &v, 8); }
+__device__ __forceinline__ void lds_st4(uint8_t *p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
+__device__ __forceinline__ uint4 lds_ld16(const uint8_t *p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }
+__device__ __forceinline__ void lds_st16(uint8_t *p, uint4 v) { __builtin_memcpy(p, &v, 16); }
+__device__ __forceinline__ void lds_st2(uint8_t *p, uint16_t v) { __builtin_memcpy(p, &v, 2); }
+
+/* store the low n (< 8) bytes of v */
+__device__ __forceinline__ void lds_st_tail(uint8_t *p, uint64_t v, uint32_t n)
+{
+	if (n & 4) { lds_st4(p, (uint32_t)v); p += 4; v >>= 32; }
+	if (n & 2) { lds_st2(p, (uint16_t)v); p += 2; v >>= 16; }
+	if (n & 1) *p = (uint8_t)v;
+}
+
+/* load n (< 8) bytes without touching bytes past p+n */
+__device__ __forceinline__ uint64_t lds_ld_tail(const uint8_t *p, uint32_t n)
+{
+	uint64_t v = 0;
+	uint32_t sh = 0;
+	if (n & 4) { uint32_t t; __builtin_memcpy(&t, p, 4); v = t; p += 4; sh = 32; }
+	if (n & 2) { uint16_t t; __builtin_memcpy(&t, p, 2); v |= (uint64_t)t << sh; p += 2; sh += 16; }
+	if (n & 1) v |= (uint64_t)(*p) << sh;
+	return v;
+}
+
 /* ---- launch interface (definitions live next to their kernels) ---- */
 
 /* la_hash.hip */
@@ -373,19 +402,9 @@ void la_launch_lz4_expand_fast_big(hipStream_t s, const uint8_t *d_src, uint64_t
     const uint32_t *d_nseq, const la_lz4_seq *d_table, const uint64_t *d_table_off,
     uint32_t *d_big /* n + 1 words */, uint32_t long_thr);
 
-/* la_lz4_fastq.hip: the same contract as the two launches above, queue generation */
-void la_launch_lz4_expand_queue(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
-    const la_lz4_block *d_blocks, uint32_t n, uint8_t *d_dst, uint64_t dst_cap,
-    const uint64_t *d_dst_off, const uint32_t *d_out_len, uint32_t *d_status,
-    const uint32_t *d_nseq, const la_lz4_seq *d_table, const uint64_t *d_table_off, uint32_t long_thr);
-void la_launch_lz4_expand_queue_big(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
-    const la_lz4_block *d_blocks, uint32_t n, uint8_t *d_dst, uint64_t dst_cap,
-    const uint64_t *d_dst_off, const uint32_t *d_out_len, uint32_t *d_status,
-    const uint32_t *d_nseq, const la_lz4_seq *d_table, const uint64_t *d_table_off,
-    uint32_t *d_big /* n + 1 words */, uint32_t long_thr);
-
-/* la_lz4_wide.hip: the same contract, global-memory window (takes blocks of any sequence count: no _big launch) */
-void la_launch_lz4_expand_wide(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
+/* la_lz4_inorder.hip: the default expand step since round 3 (in-order matcher wave + literal wave + flush wave per
+ * 64 KiB LDS window); the same contract, blocks of any sequence count (no _big launch) */
+void la_launch_lz4_expand_inorder(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
     const la_lz4_block *d_blocks, uint32_t n, uint8_t *d_dst, uint64_t dst_cap,
     const uint64_t *d_dst_off, const uint32_t *d_out_len, uint32_t *d_status,
     const uint32_t *d_nseq, const la_lz4_seq *d_table, const uint64_t *d_table_off, uint32_t long_thr);
@@ -394,11 +413,6 @@ void la_launch_lz4_expand_wide(hipStream_t s, const uint8_t *d_src, uint64_t src
 uint64_t la_zstd_workspace_bytes(uint32_t n_frames);
 void la_launch_zstd_frames(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes, const la_zstd_frame *d_frames, uint32_t n,
     uint8_t *d_dst, uint64_t dst_cap, la_zstd_result *d_results, uint8_t *ws, uint32_t options);
-
-void la_launch_lz4_expand_ring(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
-    const la_lz4_block *d_blocks, uint32_t n, uint8_t *d_dst, uint64_t dst_cap,
-    const uint64_t *d_dst_off, const uint32_t *d_out_len, uint32_t *d_status,
-    const uint32_t *d_nseq, const la_lz4_seq *d_table, const uint64_t *d_table_off, uint32_t long_thr);
 
 /* la_lz4_comp.hip */
 void la_launch_lz4_compress(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes, uint32_t block_size,

@@ -101,35 +101,6 @@ __device__ unsigned long long *la_diag_stamps;
 #define STAMP(slot) do { } while (0)
 #endif
 
-/* LDS accepts unaligned 2/4/8-byte accesses on gfx950 (the compiler emits
- * ds_read_b64 / ds_write_b64 for these), so window copies move 8 bytes per
- * instruction at any byte address. */
-__device__ __forceinline__ uint64_t lds_ld8(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
-__device__ __forceinline__ void lds_st8(uint8_t *p, uint64_t v) { __builtin_memcpy(p, &v, 8); }
-__device__ __forceinline__ void lds_st4(uint8_t *p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
-__device__ __forceinline__ uint4 lds_ld16(const uint8_t *p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }
-__device__ __forceinline__ void lds_st16(uint8_t *p, uint4 v) { __builtin_memcpy(p, &v, 16); }
-__device__ __forceinline__ void lds_st2(uint8_t *p, uint16_t v) { __builtin_memcpy(p, &v, 2); }
-
-/* store the low n (< 8) bytes of v */
-__device__ __forceinline__ void lds_st_tail(uint8_t *p, uint64_t v, uint32_t n)
-{
-	if (n & 4) { lds_st4(p, (uint32_t)v); p += 4; v >>= 32; }
-	if (n & 2) { lds_st2(p, (uint16_t)v); p += 2; v >>= 16; }
-	if (n & 1) *p = (uint8_t)v;
-}
-
-/* load n (< 8) bytes without touching bytes past p+n */
-__device__ __forceinline__ uint64_t lds_ld_tail(const uint8_t *p, uint32_t n)
-{
-	uint64_t v = 0;
-	uint32_t sh = 0;
-	if (n & 4) { uint32_t t; __builtin_memcpy(&t, p, 4); v = t; p += 4; sh = 32; }
-	if (n & 2) { uint16_t t; __builtin_memcpy(&t, p, 2); v |= (uint64_t)t << sh; p += 2; sh += 16; }
-	if (n & 1) v |= (uint64_t)(*p) << sh;
-	return v;
-}
-
 /* A sequence-table entry travels in registers as one 64-bit value
  * (lit_src | lit_len << 16 | dst << 32 | off << 48): plain integers keep the
  * compiler from parking small structs in scratch memory. */

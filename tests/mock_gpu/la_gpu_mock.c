@@ -19,7 +19,7 @@ unsigned long la_gpu_mock_hist_blocks(void) { return mock_hist_blocks; }
 struct la_gpu_ctx { char err[64]; };
 _Static_assert(sizeof(orc_xxh32_state) <= LA_XXH_CARRY_BYTES, "carry buffer too small for the oracle's state");
 
-int la_gpu_abi_version(void) { return 2; }
+int la_gpu_abi_version(void) { return LA_GPU_ABI_VERSION; }
 int la_gpu_device_count(void) { return 1; }
 int la_gpu_open(int device, la_gpu_ctx **out)
 {

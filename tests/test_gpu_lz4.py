@@ -17,24 +17,24 @@ MANIFEST = [e for e in json.load(open(os.path.join(GOLD, "manifest.json"))) if e
 
 
 def gpu_decode(ctx, image, options=None):
-    """Runs BOTH expand paths (LDS-window kernel + general kernel, and general kernel only)
-    and BOTH parse generations (LDS-staged fused parse+checksum, and the two first-generation
+    """Runs ALL THREE expand paths (in-order LDS-window kernel + general kernel, general kernel only,
+    previous-generation polling LDS-window kernel) and BOTH parse generations (LDS-staged fused parse+checksum, and the two first-generation
     kernels) and insists that all of them agree before returning the result."""
     from libarchive_amd.lz4 import decode_image
     from libarchive_amd import _native as N
     res = []
     for opt in ((0, N.LA_LZ4_OPT_GENERAL_ONLY, N.LA_LZ4_OPT_PARSE_V1,
                  N.LA_LZ4_OPT_PARSE_V1 | N.LA_LZ4_OPT_GENERAL_ONLY,
-                 N.LA_LZ4_OPT_EXPAND_QUEUE, N.LA_LZ4_OPT_EXPAND_WIDE, N.LA_LZ4_OPT_EXPAND_RING) if options is None else (options,)):
+                 N.LA_LZ4_OPT_EXPAND_POLL) if options is None else (options,)):
         out, rc, msg, plan = decode_image(ctx, image, options=opt)
         res.append((out.tobytes(), rc, msg))
-    assert all(r == res[0] for r in res), "kernel variants disagree (expand fast/general/queue/wide x parse staged/v1)"
+    assert all(r == res[0] for r in res), "kernel variants disagree (expand in-order/general/polling x parse staged/v1)"
     return res[0]
 
 
 def test_library_is_loaded_and_device_present(gpu_ctx):
     import libarchive_amd as la
-    assert la.gpu_lib().la_gpu_abi_version() == 2
+    assert la.gpu_lib().la_gpu_abi_version() == 3
     assert la.gpu_lib().la_gpu_device_count() >= 1
 
 

@@ -37,7 +37,7 @@ def test_every_declared_symbol_is_exported(header, lib):
 def test_abi_struct_sizes():
     assert N.LZ4_BLOCK_DTYPE.itemsize == 24 and N.LZ4_FRAME_DTYPE.itemsize == 32
     assert N.GZ_MEMBER_DTYPE.itemsize == 24 and N.GZ_RESULT_DTYPE.itemsize == 16
-    assert la.gpu_lib().la_gpu_abi_version() == 2
+    assert la.gpu_lib().la_gpu_abi_version() == 3
 
 
 @pytest.mark.parametrize("read_size", [1, 2, 7, 200, 65536, None])
