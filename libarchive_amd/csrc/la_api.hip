@@ -341,7 +341,8 @@ int la_gpu_lz4_decode(la_gpu_ctx *c, const la_lz4_batch *bt)
 		return LA_ERR_ARG;
 	const bool fast = !(bt->options & LA_LZ4_OPT_GENERAL_ONLY);
 	const bool verify = !(bt->options & LA_LZ4_OPT_NO_VERIFY);
-	const bool poll = (bt->options & LA_LZ4_OPT_EXPAND_POLL) != 0;	/* previous-generation expand kernel (cross-check) */
+	/* previous-generation expand kernel: on request (cross-check), and for images of less than 16 bytes */
+	const bool poll = (bt->options & LA_LZ4_OPT_EXPAND_POLL) != 0 || !la_lz4_expand_inorder_takes(bt->src_bytes);
 	lz4_ws w;
 	lz4_ws_layout(&w, NULL, bt->n_blocks, bt->src_bytes, fast);
 	if (w.total > c->ws_bytes) {

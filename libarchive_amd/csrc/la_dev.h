@@ -404,6 +404,7 @@ void la_launch_lz4_expand_fast_big(hipStream_t s, const uint8_t *d_src, uint64_t
 
 /* la_lz4_inorder.hip: the default expand step since round 3 (in-order matcher wave + literal wave + flush wave per
  * 64 KiB LDS window); the same contract, blocks of any sequence count (no _big launch) */
+bool la_lz4_expand_inorder_takes(uint64_t src_bytes);	/* false: image too short for it, use the polling kernel */
 void la_launch_lz4_expand_inorder(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
     const la_lz4_block *d_blocks, uint32_t n, uint8_t *d_dst, uint64_t dst_cap,
     const uint64_t *d_dst_off, const uint32_t *d_out_len, uint32_t *d_status,

@@ -44,14 +44,21 @@
 #ifndef IO_BPW
 #define IO_BPW 8u		/* consecutive blocks one workgroup takes */
 #endif
-#define IO_THREADS 192
+#ifndef IO_LWAVES
+#define IO_LWAVES 6u		/* literal waves per workgroup */
+#endif
+/* M + L waves + F work; the workgroup is launched with eight waves all the same (the rest leave at once): with two
+ * workgroups of SIX waves per CU the compiler derives "3 waves per SIMD" from the LDS size and pads the register
+ * allocation to 129 so that no fourth wave fits -- and then the second workgroup's 2+2+1+1 waves do not fit beside
+ * the first's (measured: one workgroup per CU).  Eight waves per workgroup make it 4 per SIMD, 2 per SIMD and group. */
+#define IO_THREADS 512u
 #define IO_SPIN_LIMIT (1u << 22)
-#ifndef IO_MAX_EXACT
-#define IO_MAX_EXACT 8		/* unfinished lanes after pass 1 up to which the exact dependency masks are built */
+#ifndef IO_RING
+#define IO_RING 8u		/* groups of 64 sequence records L may be ahead of M */
 #endif
 
 struct io_ctl {
-	uint32_t lit_total;	/* groups of 64 sequences whose literals are in the window (monotonic over the workgroup's blocks) */
+	uint32_t match_groups;	/* groups M is done with (same count) */
 	uint32_t match_flag;	/* (processed-block counter & 0x7FFF) << 17 | window position up to which all bytes are final */
 	uint32_t flushed;	/* processed blocks whose window has been read out completely */
 	uint32_t abort;		/* a wave gave up: everybody leaves */
@@ -59,14 +66,22 @@ struct io_ctl {
 
 #ifdef LA_DIAG
 __device__ unsigned long long *la_diag_io_stamps;
-#define IO_STAMP_ADD(slot, v)                                                                     \
+/* counters are kept in registers and written out once per workgroup (a read-modify-write of global
+ * memory per stamp would cost more than what it measures) */
+#define IO_STAMP_DECL unsigned long long io_acc[16] = { 0 }
+#define IO_STAMP_ADD(slot, v) (io_acc[slot] += (unsigned long long)(v))
+#define IO_STAMP_FLUSH()                                                                          \
 	do {                                                                                      \
 		if (lane == 0 && la_diag_io_stamps)                                               \
-			la_diag_io_stamps[(size_t)blockIdx.x * 16 + (slot)] += (unsigned long long)(v); \
+			for (int q_ = 0; q_ < 16; q_++)                                           \
+				if (io_acc[q_])                                                   \
+					atomicAdd(&la_diag_io_stamps[(size_t)blockIdx.x * 16 + q_], io_acc[q_]); \
 	} while (0)
 #define IO_NOW() __builtin_readcyclecounter()
 #else
+#define IO_STAMP_DECL do { } while (0)
 #define IO_STAMP_ADD(slot, v) do { } while (0)
+#define IO_STAMP_FLUSH() do { } while (0)
 #define IO_NOW() 0ull
 #endif
 
@@ -75,11 +90,6 @@ typedef uint64_t seq_t;
 #define SEQ_LIT_LEN(e) ((uint32_t)(((e) >> 16) & 0xFFFFu))
 #define SEQ_DST(e)     ((uint32_t)(((e) >> 32) & 0xFFFFu))
 #define SEQ_OFF(e)     ((uint32_t)((e) >> 48))
-
-__device__ __forceinline__ seq_t io_ent(const la_lz4_seq *t, uint32_t k, uint32_t ns)
-{
-	return k < ns ? *(const uint64_t *)(const void *)(t + k) : 0ull;
-}
 
 __device__ __forceinline__ uint32_t io_ld(const uint32_t *p)
 {
@@ -94,8 +104,9 @@ __device__ __forceinline__ void io_st(uint32_t *p, uint32_t v)
 __device__ __forceinline__ bool io_wait_ge(const uint32_t *p, uint32_t want, io_ctl *ctl, uint32_t sleep)
 {
 	uint32_t spins = 0;
-	while ((int32_t)(io_ld(p) - want) < 0) {
-		if (++spins > IO_SPIN_LIMIT || io_ld(&ctl->abort))
+	/* (the words are the same in every lane: readfirstlane tells the compiler so, and the loop is scalar) */
+	while ((int32_t)((uint32_t)__builtin_amdgcn_readfirstlane((int)io_ld(p)) - want) < 0) {
+		if (++spins > IO_SPIN_LIMIT || __builtin_amdgcn_readfirstlane((int)io_ld(&ctl->abort)))
 			return false;
 		if (sleep)
 			__builtin_amdgcn_s_sleep(2);
@@ -142,31 +153,31 @@ __device__ __forceinline__ io_blk io_load_blk(uint32_t bi, uint32_t n, const uin
 }
 
 /* exact-length copy inside the window, ranges do not overlap (n <= distance), n >= 1.  Every load of a
- * trip is issued before its stores; 16-byte pieces from 16 bytes up with the last one placed so that it
- * ENDS with the copy (overlapping stores instead of a ragged tail), two 8-byte accesses below that, two
- * 4-byte ones below 8: an unaligned LDS access costs one cycle per active lane whatever its width
- * (profiles/r02_ubench_lds.txt).  Loads may run up to 15 bytes past the source (window bytes or the slack
- * behind the window); stores never pass d + n. */
+ * trip is issued before its stores (the conditional loads start from zeros, not from the first load's
+ * value: nothing makes one DS read wait for another); 16-byte pieces from 16 bytes up with the last one
+ * placed so that it ENDS with the copy (overlapping stores instead of a ragged tail), two 8-byte accesses
+ * below that, two 4-byte ones below 8: an unaligned LDS access costs one cycle per active lane whatever
+ * its width (profiles/r02_ubench_lds.txt).  Loads may run up to 15 bytes past the source (window bytes or
+ * the slack behind the window); stores never pass d + n. */
 __device__ __forceinline__ void io_copy_exact(uint8_t *d, const uint8_t *s, uint32_t n)
 {
 	if (n >= 16) {
 		for (uint32_t i = 0;; i += 32) {	/* one trip up to 47 bytes */
 			const uint32_t left = n - i;
+			const bool two = left >= 32, last = left < 48, rag = last && (left & 15);
 			const uint4 v0 = lds_ld16(s + i);
-			uint4 v1 = v0, vt = v0;
-			if (left >= 32)
+			uint4 v1 = make_uint4(0, 0, 0, 0), vt = make_uint4(0, 0, 0, 0);
+			if (two)
 				v1 = lds_ld16(s + i + 16);
-			const bool last = left < 48;
-			if (last && (left & 15))
+			if (rag)
 				vt = lds_ld16(s + n - 16);
 			lds_st16(d + i, v0);
-			if (left >= 32)
+			if (two)
 				lds_st16(d + i + 16, v1);
-			if (last) {
-				if (left & 15)
-					lds_st16(d + n - 16, vt);
+			if (rag)
+				lds_st16(d + n - 16, vt);
+			if (last)
 				break;
-			}
 		}
 	} else if (n >= 8) {
 		const uint64_t a0 = lds_ld8(s), at = lds_ld8(s + n - 8);
@@ -203,6 +214,107 @@ __device__ __forceinline__ void io_copy_match(uint8_t *mp, uint32_t off, uint32_
 	} while (done < mlen);
 }
 
+/* The usual match -- at most 64 bytes, not overlapping its source -- as ONE straight line of predicated DS
+ * instructions.  A wave on its own issues an instruction every four or five cycles and pays an instruction-fetch
+ * restart for every taken branch, and the matcher's passes are nothing but this copy: what the compiler makes of
+ * `if (class) copy piece` is three to eight instructions and up to two branches per piece.  Here a piece is two:
+ * exec = ready lanes of the class (both wave-uniform masks, the class masks worked out once per group), then the
+ * DS instruction; no branch.  All loads are issued before anything is stored, pieces as in io_copy_exact:
+ * 16-byte pieces at 0 / 16 / 32 and one that ENDS with the match, 8 + 8 overlapping below 16 bytes, 4 + 4 below 8,
+ * 2 + 1 below 4 (1..3 bytes: only the deflate front end makes these). */
+typedef uint32_t io_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t io_u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) uint8_t io_lds_u8;
+__device__ __forceinline__ uint32_t io_lds_addr(const uint8_t *p) { return (uint32_t)(uintptr_t)(const io_lds_u8 *)p; }
+
+struct io_cls {		/* lanes of the group by length class, fast lanes only (wave-uniform, one SGPR pair each) */
+	uint64_t k16, k32, k48, ke;	/* >= 16, >= 32, >= 48, end piece (length > 16 and not 32 or 48) */
+	uint64_t ks, ks8, ks88;		/* < 16 (8-byte load), 8..15, 9..15 */
+	uint64_t ks4, ks44, k2, k1;	/* 4..7, 5..7, {2,3}, {1,3} */
+};
+struct io_adr {		/* per lane: LDS byte addresses and shift counts */
+	uint32_t fp, mp;	/* source, destination */
+	uint32_t fe, me;	/* + length - 16 */
+	uint32_t f8, m8;	/* + length - 8 */
+	uint32_t m4, sh4;	/* mp + length - 4, 8 * (length - 4) */
+	uint32_t m1, sh1;	/* mp + (length & 2), 8 * (length & 2) */
+};
+
+/* one predicated DS instruction: exec = ready lanes of the class, then the instruction (IO_EXP_SKIP_EMPTY: the
+ * instruction is jumped over when no lane is left -- a timing experiment, see profiles/r03_inorder_whatif.txt) */
+#ifdef IO_EXP_SKIP_EMPTY
+#define IO_DS(mask_, ins_, n_) "s_and_b64 exec, %[R], %[" mask_ "]\n\ts_cbranch_execz .Lio" n_ "_%=\n\t" ins_ "\n\t.Lio" n_ "_%=:\n\t"
+#else
+#define IO_DS(mask_, ins_, n_) "s_and_b64 exec, %[R], %[" mask_ "]\n\t" ins_ "\n\t"
+#endif
+__device__ __forceinline__ void io_copy_fast(const uint64_t R, const io_cls &K, const io_adr &A)
+{
+	io_u32x4 v0, v1, v2, vt;
+	io_u32x2 a0, at;
+	uint64_t sv;
+	asm volatile(
+	    "s_mov_b64 %[sv], exec\n\t"
+	    IO_DS("k16", "ds_read_b128 %[v0], %[fp]", "0")
+	    IO_DS("k32", "ds_read_b128 %[v1], %[fp] offset:16", "1")
+	    IO_DS("k48", "ds_read_b128 %[v2], %[fp] offset:32", "2")
+	    IO_DS("ke", "ds_read_b128 %[vt], %[fe]", "3")
+	    IO_DS("ks", "ds_read_b64 %[a0], %[fp]", "4")
+	    IO_DS("ks88", "ds_read_b64 %[at], %[f8]", "5")
+	    "s_mov_b64 exec, %[sv]\n\t"
+	    "s_waitcnt lgkmcnt(0)"
+	    : [sv] "=&s"(sv), [v0] "=&v"(v0), [v1] "=&v"(v1), [v2] "=&v"(v2), [vt] "=&v"(vt), [a0] "=&v"(a0), [at] "=&v"(at)
+	    : [R] "s"(R), [k16] "s"(K.k16), [k32] "s"(K.k32), [k48] "s"(K.k48), [ke] "s"(K.ke), [ks] "s"(K.ks), [ks88] "s"(K.ks88),
+	      [fp] "v"(A.fp), [fe] "v"(A.fe), [f8] "v"(A.f8)
+	    : "memory");
+	/* (lanes outside a class hold garbage in that class's registers: never stored) */
+#ifdef IO_EXP_LOADS_ONLY	/* timing experiment */
+	asm volatile("" :: "v"(v0), "v"(v1), "v"(v2), "v"(vt), "v"(a0), "v"(at));
+	return;
+#endif
+	const uint32_t a0lo = a0.x;
+	const uint32_t t4 = (uint32_t)((((uint64_t)a0.y << 32) | a0.x) >> (A.sh4 & 63u));
+	const uint32_t t1 = a0lo >> (A.sh1 & 31u);
+	asm volatile(
+	    "s_mov_b64 %[sv], exec\n\t"
+	    IO_DS("k16", "ds_write_b128 %[mp], %[v0]", "0")
+	    IO_DS("k32", "ds_write_b128 %[mp], %[v1] offset:16", "1")
+	    IO_DS("k48", "ds_write_b128 %[mp], %[v2] offset:32", "2")
+	    IO_DS("ke", "ds_write_b128 %[me], %[vt]", "3")
+	    IO_DS("ks8", "ds_write_b64 %[mp], %[a0]", "4")
+	    IO_DS("ks88", "ds_write_b64 %[m8], %[at]", "5")
+	    IO_DS("ks4", "ds_write_b32 %[mp], %[a0lo]", "6")
+	    IO_DS("ks44", "ds_write_b32 %[m4], %[t4]", "7")
+	    IO_DS("k2", "ds_write_b16 %[mp], %[a0lo]", "8")
+	    IO_DS("k1", "ds_write_b8 %[m1], %[t1]", "9")
+	    "s_mov_b64 exec, %[sv]"
+	    : [sv] "=&s"(sv)
+	    : [R] "s"(R), [k16] "s"(K.k16), [k32] "s"(K.k32), [k48] "s"(K.k48), [ke] "s"(K.ke), [ks8] "s"(K.ks8), [ks88] "s"(K.ks88),
+	      [ks4] "s"(K.ks4), [ks44] "s"(K.ks44), [k2] "s"(K.k2), [k1] "s"(K.k1),
+	      [mp] "v"(A.mp), [me] "v"(A.me), [m8] "v"(A.m8), [m4] "v"(A.m4), [m1] "v"(A.m1),
+	      [v0] "v"(v0), [v1] "v"(v1), [v2] "v"(v2), [vt] "v"(vt), [a0] "v"(a0), [at] "v"(at), [a0lo] "v"(a0lo), [t4] "v"(t4), [t1] "v"(t1)
+	    : "memory");
+}
+#undef IO_DS
+
+/* v >> (8 * bytes) over 128 bits, bytes >= 16 gives zeros (only the last 16 bytes of an image need it) */
+__device__ __forceinline__ uint4 io_shr128(uint4 v, uint32_t bytes)
+{
+	uint32_t w[8] = { v.x, v.y, v.z, v.w, 0, 0, 0, 0 };
+	for (; bytes >= 4 && bytes < 32; bytes -= 4) {
+		w[0] = w[1]; w[1] = w[2]; w[2] = w[3]; w[3] = 0;
+	}
+	if (bytes >= 32)
+		return make_uint4(0, 0, 0, 0);
+	const uint32_t sh = 8 * bytes;
+	if (sh) {
+		w[0] = (w[0] >> sh) | (w[1] << (32 - sh));
+		w[1] = (w[1] >> sh) | (w[2] << (32 - sh));
+		w[2] = (w[2] >> sh) | (w[3] << (32 - sh));
+		w[3] = w[3] >> sh;
+	}
+	return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 /* exact-length literal store of 1..32 bytes: p0 = payload bytes [0, 16), pt = bytes [ll - 16, ll) when
  * ll > 16 */
 __device__ __forceinline__ void io_lit_store(uint8_t *d, const uint4 p0, const uint4 pt, uint32_t ll)
@@ -227,18 +339,7 @@ __device__ __forceinline__ void io_lit_store(uint8_t *d, const uint4 p0, const u
 	}
 }
 
-/* 16 payload bytes at p; the last few bytes of the image are assembled byte by byte (never read past it) */
-__device__ __forceinline__ uint4 io_ld_payload16(const uint8_t *s, uint32_t at, uint64_t s_room)
-{
-	if ((uint64_t)at + 16 <= s_room)
-		return ld_u128(s + at);
-	uint32_t w[4] = { 0, 0, 0, 0 };
-	for (uint32_t i = 0; i < 16 && (uint64_t)at + i < s_room; i++)
-		w[i >> 2] |= (uint32_t)s[at + i] << (8 * (i & 3));
-	return make_uint4(w[0], w[1], w[2], w[3]);
-}
-
-__global__ __launch_bounds__(IO_THREADS) void lz4_expand_inorder_kernel(
+__global__ __launch_bounds__(IO_THREADS, 4) void lz4_expand_inorder_kernel(
     const uint8_t *__restrict__ src, uint64_t src_bytes, const la_lz4_block *__restrict__ blocks,
     uint32_t n, uint8_t *__restrict__ dst, uint64_t dst_cap, const uint64_t *__restrict__ dst_off,
     const uint32_t *__restrict__ out_len, uint32_t *status_out,
@@ -248,113 +349,190 @@ __global__ __launch_bounds__(IO_THREADS) void lz4_expand_inorder_kernel(
 	const uint32_t *status = status_out;
 	/* 16 bytes of headroom + up to 15 of alignment shift + the window + slack for over-reads */
 	__shared__ __attribute__((aligned(16))) uint8_t win[16 + 16 + 65536 + 96];
+	/* what L has worked out for M, one 16-byte record per sequence, IO_RING groups deep:
+	 *   x = match destination (17 bits) | first << 17 | last << 23 | dep << 29: the lanes first..last of the group
+	 *       are the ones whose matches the source of this match overlaps (dep = 0: none);
+	 *   y = match length, z = match offset, w = running number of the group + 1 -- the tag that tells M the
+	 *       record is there: a group's records are written by ONE ds_write_b128, after its literals. */
+	__shared__ __attribute__((aligned(16))) uint4 ring[IO_RING][64];
 	__shared__ io_ctl ctl_s;
 	io_ctl *const ctl = &ctl_s;
 
 	const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	if (tid == 0) {
-		ctl->lit_total = 0;
+		ctl->match_groups = 0;
 		ctl->match_flag = 0x7FFFu << 17;	/* no block has this number first */
 		ctl->flushed = 0;
 		ctl->abort = 0;
 	}
+	for (uint32_t i = tid; i < IO_RING * 64u; i += IO_THREADS)
+		ring[i >> 6][i & 63] = make_uint4(0, 0, 0, 0);	/* no group has tag 0 */
 	__syncthreads();	/* the only barrier: the roles part here */
 
 	const uint32_t b_first = blockIdx.x * IO_BPW;
+	bool dead = false;	/* wave-uniform: this wave has seen a failure (its own or the abort word) */
+	IO_STAMP_DECL;
 
 #define IO_LOAD_BLK(bi_) io_load_blk((bi_), n, src, src_bytes, blocks, dst, dst_cap, dst_off, out_len, status, nseq, table, table_off, long_thr)
+/* A wave that gives up marks the block and raises the abort word; it does NOT leave (hipcc 7.2 miscompiled the
+ * literal waves' loop-carried prefetch registers around an early return inside the group loop: after the first
+ * ring wait the next group's literal bytes were replaced by the current group's -- found with the reference's
+ * test_compat_lz4_B4 fixture).  From then on every wait of every wave falls through at once, matches and literals
+ * are skipped (dead), and the workgroup runs out quickly; the block's status tells the host. */
+#define IO_FAIL(bi_)                                          \
+	do {                                                  \
+		if (lane == 0) {                              \
+			status_out[bi_] = LA_ST_LZ4_DECODE;   \
+			io_st(&ctl->abort, 1);                \
+		}                                             \
+		dead = true;                                  \
+	} while (0)
 
 	if (wave == 0) {
 		/* ================= M: matches, in stream order ================= */
 		__builtin_amdgcn_s_setprio(3);
+#ifdef LA_DIAG
+		io_acc[12] = __builtin_amdgcn_s_memrealtime();
+#endif
 		uint32_t gbase = 0, seqno = 0;
+		uint4 xn = ring[0][lane];	/* the next group's records, requested a group ahead */
 		for (uint32_t it = 0; it < IO_BPW; it++) {
 			const uint32_t bi = b_first + it;
 			const io_blk B = IO_LOAD_BLK(bi);
 			if (!B.take)
 				continue;
 			uint8_t *const W = win + 16 + ((uintptr_t)B.g_out & 15);	/* W[i] <-> g_out[i], congruent mod 16 */
-			const uint32_t ns = B.ns, olen = B.olen;
-			const uint32_t ng = (ns + 63) >> 6;
-			seq_t e0 = io_ent(B.tab, lane, ns), e1 = io_ent(B.tab, 64 + lane, ns);
-			const unsigned long long t_blk0 = IO_NOW();
+			const uint32_t w_lds = io_lds_addr(W);
+			const uint32_t ng = (B.ns + 63) >> 6;
+			[[maybe_unused]] const unsigned long long t_blk0 = IO_NOW();
 			for (uint32_t g = 0; g < ng; g++) {
-				const seq_t e2 = io_ent(B.tab, (g + 2) * 64 + lane, ns);
-				const uint32_t k = g * 64 + lane;
-				const bool valid = k < ns;
-				/* where the next group's output begins = where this group's ends */
-				const uint32_t s_next = (g + 1) * 64 < ns ? (uint32_t)__builtin_amdgcn_readfirstlane((int)SEQ_DST(e1)) : olen;
-				const uint32_t d = valid ? SEQ_DST(e0) : olen;
-				const uint32_t ll = SEQ_LIT_LEN(e0), off = SEQ_OFF(e0);
-				const uint32_t mdst = d + ll;
-				/* output position of the next sequence: lane + 1's, the next group's first for lane 63 */
-				uint32_t nd = (uint32_t)__builtin_amdgcn_update_dpp((int)s_next, (int)d, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-				if (k + 1 >= ns)
-					nd = olen;	/* the last sequence ends with the block */
-				uint32_t mlen = (valid && nd > mdst && nd <= olen) ? nd - mdst : 0;
-				/* a table entry that does not add up (impossible for one the parse kernel wrote) */
-				const bool bad = valid && (mdst > olen || nd < mdst || (mlen != 0 && (off == 0 || off > mdst)));
-				if (__ballot(bad) != 0) {
-					if (lane == 0) {
-						status_out[bi] = LA_ST_LZ4_DECODE;
-						io_st(&ctl->abort, 1);
+				const uint32_t G = gbase + g;
+				/* L has to be past this group (it normally is, by several groups: then the records came with
+				 * the previous group's loads).  All 64 records of a group appear at once. */
+				[[maybe_unused]] const unsigned long long t_w0 = IO_NOW();
+#ifdef IO_DBG_NOPREFETCH
+				asm volatile("" ::: "memory");
+				uint4 x = ring[G % IO_RING][lane];
+#else
+				uint4 x = xn;
+#endif
+				for (uint32_t spins = 0; __ballot(x.w == G + 1) != ~0ull;) {
+					if (++spins > IO_SPIN_LIMIT || __builtin_amdgcn_readfirstlane((int)io_ld(&ctl->abort))) {
+						IO_FAIL(bi);
+						break;
 					}
-					return;
+					asm volatile("" ::: "memory");
+					x = ring[G % IO_RING][lane];
 				}
-				const uint32_t s0 = mdst - off;
-				const uint32_t send = s0 + (mlen < off ? mlen : off);	/* first byte behind the part of the source that exists before the copy starts */
-				bool fin = mlen == 0;
-
-				/* L has to be past this group (it normally is, by a group or more) */
-				const unsigned long long t_w0 = IO_NOW();
-				if (!io_wait_ge(&ctl->lit_total, gbase + g + 1, ctl, 0)) {
-					if (lane == 0) {
-						status_out[bi] = LA_ST_LZ4_DECODE;
-						io_st(&ctl->abort, 1);
-					}
-					return;
-				}
+				if (dead)
+					x = make_uint4(0, 0, 0, 0);	/* nothing to copy */
 				IO_STAMP_ADD(1, IO_NOW() - t_w0);
 				asm volatile("" ::: "memory");
+				const uint32_t mdst = x.x & 0x1FFFFu, mlen = x.y, off = x.z;
+				const uint32_t d_lo = (x.x >> 17) & 63u, d_hi = (x.x >> 23) & 63u;
+				const bool dep = (x.x >> 29) & 1u;
+				/* the lanes this one has to wait for, as a mask */
+#ifdef IO_DBG_NODEP	/* every lower lane counts as a dependency */
+				const uint64_t rmask = (1ull << lane) - 1ull;
+				(void)dep; (void)d_hi; (void)d_lo;
+#else
+				const uint64_t rmask = dep ? (2ull << d_hi) - (1ull << d_lo) : 0ull;
+#endif
+				bool fin = mlen == 0;
+				uint8_t *const mp = W + mdst;
+				const bool slow = mlen > 64 || off < mlen;
+				const uint32_t mf = (mlen != 0 && !slow) ? mlen : 0u;	/* length if the straight-line copy takes the match */
+				io_cls K;
+				K.k16 = __ballot(mf >= 16);
+				K.k32 = __ballot(mf >= 32);
+				K.k48 = __ballot(mf >= 48);
+				K.ke = __ballot(mf > 16 && mf != 32 && mf != 48);
+				K.ks = __ballot(mf != 0 && mf < 16);
+				K.ks8 = __ballot(mf >= 8 && mf < 16);
+				K.ks88 = __ballot(mf > 8 && mf < 16);
+				K.ks4 = __ballot(mf >= 4 && mf < 8);
+				K.ks44 = __ballot(mf > 4 && mf < 8);
+				K.k2 = __ballot(mf != 0 && mf < 4 && (mf & 2));
+				K.k1 = __ballot(mf != 0 && mf < 4 && (mf & 1));
+				const uint64_t kslow = __ballot(slow && mlen != 0);
+				io_adr A;
+				A.mp = w_lds + mdst;
+				A.fp = A.mp - off;
+				A.me = A.mp + mlen - 16;
+				A.fe = A.fp + mlen - 16;
+				A.m8 = A.mp + mlen - 8;
+				A.f8 = A.fp + mlen - 8;
+				A.m4 = A.mp + mlen - 4;
+				A.sh4 = 8 * (mlen - 4);
+				A.m1 = A.mp + (mlen & 2);
+				A.sh1 = 8 * (mlen & 2);
+				/* the next group's records travel with this group's first loads */
+				asm volatile("" ::: "memory");
+				xn = ring[(G + 1) % IO_RING][lane];
+				asm volatile("" ::: "memory");
+				[[maybe_unused]] const unsigned long long t_p0 = IO_NOW();
+				[[maybe_unused]] unsigned long long t_p1 = t_p0;
 
-				/* pass 1: every match whose source lies in front of the group's first match.  Rounds: a
-				 * lane is ready when its source ends in front of the match of the lowest unfinished lane */
-				uint32_t P = (uint32_t)__builtin_amdgcn_readfirstlane((int)mdst);
+				/* pass 1: every match whose source does not reach into a match of its own group.  Then rounds:
+				 * a lane is ready when none of the lanes it waits for is unfinished (the lowest unfinished
+				 * lane always is) */
+				uint64_t unf = __ballot(!fin);
 				uint32_t rounds = 0;
-				for (;;) {
-					const bool ready = !fin && send <= P;
-					if (ready)
-						io_copy_match(W + mdst, off, mlen);
+				while (unf) {
+					const bool ready = !fin && (rmask & unf) == 0;
+					const uint64_t R = __ballot(ready);
+#ifndef IO_EXP_NO_COPY	/* timing experiment */
+					io_copy_fast(R, K, A);
+#endif
+					if (R & kslow) {	/* longer than 64 bytes or overlapping its source: rare */
+						if (ready && slow)
+							io_copy_match(mp, off, mlen);
+					}
 					fin = fin || ready;
 					asm volatile("" ::: "memory");
-					const uint64_t unf = __ballot(!fin);
-					if (unf == 0)
+#ifdef LA_DIAG
+					if (rounds == 0) t_p1 = IO_NOW();
+#endif
+#ifdef IO_EXP_NO_LATE	/* timing experiment: one pass only (wrong output) */
+					break;
+#endif
+					unf &= ~R;
+					if (R == 0 || ++rounds > 64u) {	/* cannot happen: the lowest unfinished lane is always ready */
+						IO_FAIL(bi);
 						break;
-					const uint32_t low = (uint32_t)__builtin_ctzll(unf);
-					P = (uint32_t)__builtin_amdgcn_readlane((int)mdst, (int)low);
-					if (++rounds > 64u) {	/* cannot happen: the lowest unfinished lane is always ready */
-						if (lane == 0) {
-							status_out[bi] = LA_ST_LZ4_DECODE;
-							io_st(&ctl->abort, 1);
-						}
-						return;
 					}
 				}
-				IO_STAMP_ADD(2, rounds + 1);
-				/* everything below s_next is final */
+				IO_STAMP_ADD(2, rounds);
+#ifdef LA_DIAG
+				IO_STAMP_ADD(6, t_p1 - t_p0);
+				IO_STAMP_ADD(7, IO_NOW() - t_p1);
+#endif
+				/* everything below the end of the group's last sequence is final */
+				const uint32_t s_next = (uint32_t)__builtin_amdgcn_readlane((int)(mdst + mlen), 63);
 				asm volatile("" ::: "memory");
-				if (lane == 0)
+				if (lane == 0) {
 					io_st(&ctl->match_flag, ((seqno & 0x7FFFu) << 17) | s_next);
-				e0 = e1;
-				e1 = e2;
+					io_st(&ctl->match_groups, G + 1);
+				}
 			}
 			IO_STAMP_ADD(0, IO_NOW() - t_blk0);
 			IO_STAMP_ADD(3, ng);
 			gbase += ng;
 			seqno++;
 		}
-	} else if (wave == 1) {
-		/* ================= L: literals, one group (or more) ahead of M ================= */
+#ifdef LA_DIAG
+		io_acc[13] = __builtin_amdgcn_s_memrealtime();
+#endif
+		IO_STAMP_FLUSH();
+	} else if (wave <= IO_LWAVES) {
+		/* ================= L: table + literals, several groups ahead of M =================
+		 * IO_LWAVES waves share the groups out by their running number G (wave j takes G % IO_LWAVES == j);
+		 * each keeps the entries two of its groups ahead and the literal bytes one ahead, every load
+		 * unconditional (indices and addresses are clamped into the table / the image, not predicated):
+		 * one global round trip per iteration and wave, IO_LWAVES groups per round trip.  Per group: literals
+		 * into the window, then what M needs to know about the matches (where, how long, from where, and which
+		 * matches of the same group each one has to wait for) as one record per sequence. */
+		const uint32_t lw = wave - 1;
 		uint32_t gbase = 0, seqno = 0;
 		for (uint32_t it = 0; it < IO_BPW; it++) {
 			const uint32_t bi = b_first + it;
@@ -362,50 +540,91 @@ __global__ __launch_bounds__(IO_THREADS) void lz4_expand_inorder_kernel(
 			if (!B.take)
 				continue;
 			uint8_t *const W = win + 16 + ((uintptr_t)B.g_out & 15);
-			const uint32_t ns = B.ns;
+			const uint32_t ns = B.ns, olen = B.olen;
 			const uint32_t ng = (ns + 63) >> 6;
 			const uint8_t *const s = B.s;
 			const uint64_t s_room = B.s_room;
-			seq_t e0 = io_ent(B.tab, lane, ns), e1 = io_ent(B.tab, 64 + lane, ns);
-			/* the first group's literal bytes are requested before the window is even free */
-			uint4 p0 = make_uint4(0, 0, 0, 0), pt = p0;
-			{
-				const uint32_t ls = SEQ_LIT_SRC(e0), ll = SEQ_LIT_LEN(e0);
-				if (ll) {
-					p0 = io_ld_payload16(s, ls, s_room);
-					if (ll > 16)
-						pt = io_ld_payload16(s, ls + (ll > 32 ? 32u : ll) - 16, s_room);
-				}
-			}
+			/* loads of 16 payload bytes never leave the image: an address closer than 16 bytes to its
+			 * end is pulled back (dmax may be negative: the image is at least 16 bytes, the launcher sees
+			 * to that) and the bytes are shifted down when they are used */
+			const int64_t dm64 = (int64_t)s_room - 16;
+			const int32_t dmax = dm64 > 0x7FFFFFFFll ? 0x7FFFFFFF : (int32_t)dm64;
+			const uint64_t *const tab64 = (const uint64_t *)(const void *)B.tab;
+#define IO_LOAD_E(grp_) tab64[((grp_) * 64 + lane) < ns ? ((grp_) * 64 + lane) : ns - 1]
+#define IO_LOAD_N(grp_) tab64[((grp_) + 1) * 64 < ns ? ((grp_) + 1) * 64 : ns - 1]	/* first entry of the group behind it */
+#define IO_LOAD_P(p0_, pt_, sh0_, sht_, e_)                                                               \
+	do {                                                                                              \
+		const uint32_t ls_ = SEQ_LIT_SRC(e_), ll_ = SEQ_LIT_LEN(e_);                              \
+		const int32_t a0_ = (int32_t)ls_ < dmax ? (int32_t)ls_ : dmax;                            \
+		const uint32_t tl_ = ll_ > 32u ? ls_ + 16u : (ll_ > 16u ? ls_ + ll_ - 16u : ls_);         \
+		const int32_t at_ = (int32_t)tl_ < dmax ? (int32_t)tl_ : dmax;                            \
+		p0_ = ld_u128(s + a0_);                                                                   \
+		pt_ = ld_u128(s + at_);                                                                   \
+		sh0_ = ls_ - (uint32_t)a0_;                                                               \
+		sht_ = tl_ - (uint32_t)at_;                                                               \
+	} while (0)
+			const uint32_t g0 = (lw + IO_LWAVES - (gbase % IO_LWAVES)) % IO_LWAVES;	/* this wave's first group of the block */
+			/* prologue: the first groups' entries and literal bytes are requested before the window is
+			 * even free */
+			seq_t eA = IO_LOAD_E(g0), nA = IO_LOAD_N(g0);
+			seq_t eB = IO_LOAD_E(g0 + IO_LWAVES), nB = IO_LOAD_N(g0 + IO_LWAVES);
+			uint4 pA0, pAt;
+			uint32_t shA0, shAt;
+			IO_LOAD_P(pA0, pAt, shA0, shAt, eA);
 			/* the window is ours when F has read the previous block out */
-			const unsigned long long t_w0 = IO_NOW();
-			if (!io_wait_ge(&ctl->flushed, seqno, ctl, 1)) {
-				if (lane == 0) {
-					status_out[bi] = LA_ST_LZ4_DECODE;
-					io_st(&ctl->abort, 1);
-				}
-				return;
-			}
+			[[maybe_unused]] const unsigned long long t_w0 = IO_NOW();
+			if (!io_wait_ge(&ctl->flushed, seqno, ctl, 1))
+				IO_FAIL(bi);
 			IO_STAMP_ADD(5, IO_NOW() - t_w0);
 			asm volatile("" ::: "memory");
-			for (uint32_t g = 0; g < ng; g++) {
-				const seq_t e2 = io_ent(B.tab, (g + 2) * 64 + lane, ns);
-				/* next group's literal bytes: in flight while this group is stored */
-				uint4 q0 = make_uint4(0, 0, 0, 0), qt = q0;
-				{
-					const uint32_t ls1 = SEQ_LIT_SRC(e1), ll1 = SEQ_LIT_LEN(e1);
-					if (ll1) {
-						q0 = io_ld_payload16(s, ls1, s_room);
-						if (ll1 > 16)
-							qt = io_ld_payload16(s, ls1 + (ll1 > 32 ? 32u : ll1) - 16, s_room);
-					}
-				}
-				const uint32_t ls = SEQ_LIT_SRC(e0), ll = SEQ_LIT_LEN(e0), d = SEQ_DST(e0);
-				/* (entries beyond the table are 0: ll = 0.)  A run that would leave the window or the
-				 * payload is not stored: M fails such a block by its own checks or the hash does */
-				const bool okl = ll != 0 && d + ll <= 65536u && (uint64_t)ls + ll <= s_room;
-				if (okl) {
+			[[maybe_unused]] const unsigned long long t_l0 = IO_NOW();
+			for (uint32_t g = g0; g < ng; g += IO_LWAVES) {
+				/* entries two of this wave's groups ahead, literal bytes one ahead */
+				const seq_t eC = IO_LOAD_E(g + 2 * IO_LWAVES), nC = IO_LOAD_N(g + 2 * IO_LWAVES);
+				uint4 pB0, pBt;
+				uint32_t shB0, shBt;
+				IO_LOAD_P(pB0, pBt, shB0, shBt, eB);
+				/* this group */
+				const seq_t e = eA;
+				const uint32_t k = g * 64 + lane;
+				const bool valid = k < ns;
+				/* where the next group's output begins = where this group's ends */
+				const uint32_t s_next = (g + 1) * 64 < ns ? (uint32_t)__builtin_amdgcn_readfirstlane((int)SEQ_DST(nA)) : olen;
+				const uint32_t d = valid ? SEQ_DST(e) : olen;
+				const uint32_t ls = SEQ_LIT_SRC(e), off = SEQ_OFF(e);
+				uint32_t ll = valid ? SEQ_LIT_LEN(e) : 0u;
+				const uint32_t mdst = d + ll;
+				/* output position of the next sequence: lane + 1's, the next group's first for lane 63 */
+				uint32_t nd = (uint32_t)__builtin_amdgcn_update_dpp((int)s_next, (int)d, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+				if (k + 1 >= ns)
+					nd = olen;	/* the last sequence ends with the block */
+				/* an entry that does not add up (impossible for a table the parse kernel wrote) fails the block */
+				const bool bad = valid && (mdst > olen || nd < mdst || nd > olen || (uint64_t)ls + ll > s_room ||
+				    (nd != mdst && (off == 0 || off > mdst)));
+				if (__ballot(bad) != 0)
+					IO_FAIL(bi);
+				const uint32_t mlen = (valid && !dead) ? nd - mdst : 0u;
+				if (dead)
+					ll = 0;		/* (mdst stays as computed: only consistent positions are handed on) */
+				const uint32_t G = gbase + g;
+#ifdef IO_EXP_NO_LIT	/* timing experiment: no literal stores (wrong output) */
+				if (ll > 0x100000u) {
+#else
+				if (ll) {
+#endif
 					uint8_t *wd = W + d;
+					uint4 p0 = pA0, pt = pAt;
+#ifdef IO_DBG_SYNC_P
+					IO_LOAD_P(p0, pt, shA0, shAt, e);
+#endif
+#ifdef IO_DBG_NOSH
+					if (0) {
+#else
+					if (shA0 | shAt) {	/* inside the last 16 bytes of the image */
+#endif
+						p0 = io_shr128(p0, shA0);
+						pt = io_shr128(pt, shAt);
+					}
 					if (ll <= 32) {
 						io_lit_store(wd, p0, pt, ll);
 					} else {
@@ -420,19 +639,48 @@ __global__ __launch_bounds__(IO_THREADS) void lz4_expand_inorder_kernel(
 							lds_st16(wd + ll - 16, ld_u128(s + ls + ll - 16));
 					}
 				}
+				/* Which matches of this group does the source of each match overlap?  The matches of the group lie in
+				 * stream order: [bm, em) of lane i ends before lane i + 1's begins.  The source [s0, send) (send: the
+				 * end of the part that exists before the copy starts) meets the lanes first .. last with
+				 * first = #{i: em_i <= s0}, last = #{i: bm_i < send} - 1: two binary searches over the lanes
+				 * (ds_bpermute), run side by side.  Both counts are below this lane's own number. */
+				const uint32_t bm = valid ? mdst : olen, em = bm + mlen;
+				const uint32_t s0 = bm - off, send = s0 + (mlen < off ? mlen : off);
+				uint32_t cl = 0, ch = 0;
+#pragma unroll
+				for (uint32_t step = 32; step; step >>= 1) {
+					const uint32_t ve = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((cl + step - 1) << 2), (int)em);
+					const uint32_t vb = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((ch + step - 1) << 2), (int)bm);
+					if (ve <= s0) cl += step;
+					if (vb < send) ch += step;
+				}
+				const bool dep = mlen != 0 && cl < ch;	/* first = cl <= last = ch - 1 */
+				/* the ring slot is free when M is done with the group IO_RING places back */
+				[[maybe_unused]] const unsigned long long t_r0 = IO_NOW();
+				if (G >= IO_RING && !io_wait_ge(&ctl->match_groups, G + 1 - IO_RING, ctl, 1))
+					IO_FAIL(bi);
+				IO_STAMP_ADD(11, IO_NOW() - t_r0);
+				/* the records go out last, in one instruction: their tag tells M that the group's literals are in
+				 * the window too (the LDS runs a wave's instructions in order) */
+#ifdef IO_DBG_LWAIT
+				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
 				asm volatile("" ::: "memory");
-				if (lane == 0)
-					io_st(&ctl->lit_total, gbase + g + 1);
-				e0 = e1;
-				e1 = e2;
-				p0 = q0;
-				pt = qt;
+				ring[G % IO_RING][lane] = make_uint4(bm | (dep ? (cl << 17) | ((ch - 1) << 23) | (1u << 29) : 0u), mlen, valid ? off : 0u, G + 1);
+				asm volatile("" ::: "memory");
+				eA = eB; nA = nB;
+				eB = eC; nB = nC;
+				pA0 = pB0; pAt = pBt; shA0 = shB0; shAt = shBt;
 			}
-			IO_STAMP_ADD(4, ng);
+#undef IO_LOAD_E
+#undef IO_LOAD_N
+#undef IO_LOAD_P
+			IO_STAMP_ADD(8, IO_NOW() - t_l0);
 			gbase += ng;
 			seqno++;
 		}
-	} else {
+		IO_STAMP_FLUSH();
+	} else if (wave == IO_LWAVES + 1) {
 		/* ================= F: flush, behind M ================= */
 		uint32_t seqno = 0;
 		for (uint32_t it = 0; it < IO_BPW; it++) {
@@ -459,7 +707,20 @@ __global__ __launch_bounds__(IO_THREADS) void lz4_expand_inorder_kernel(
 				if (avail > nunits)
 					avail = nunits;
 				bool moved = false;
-				while (avail - done >= 64u || (complete && done < avail)) {
+#ifdef IO_EXP_NO_FLUSH	/* timing experiment: nothing is written out */
+				done = avail;
+#endif
+				while (avail - done >= 256u) {	/* 4 KiB at a time: four LDS reads in flight, then four stores */
+					const uint32_t u = done + lane;
+					const uint4 r0 = wsrc[u], r1 = wsrc[u + 64], r2 = wsrc[u + 128], r3 = wsrc[u + 192];
+					gdst[u] = r0;
+					gdst[u + 64] = r1;
+					gdst[u + 128] = r2;
+					gdst[u + 192] = r3;
+					done += 256u;
+					moved = true;
+				}
+				while (complete && done < avail) {	/* the last, partial 4 KiB */
 					const uint32_t u = done + lane;
 					if (u < avail)
 						gdst[u] = wsrc[u];
@@ -478,13 +739,11 @@ __global__ __launch_bounds__(IO_THREADS) void lz4_expand_inorder_kernel(
 				}
 				if (moved) {
 					spins = 0;
-				} else if (++spins > IO_SPIN_LIMIT || io_ld(&ctl->abort)) {
-					if (lane == 0) {
-						status_out[bi] = LA_ST_LZ4_DECODE;
-						io_st(&ctl->abort, 1);
-					}
-					return;
+				} else if (++spins > IO_SPIN_LIMIT || __builtin_amdgcn_readfirstlane((int)io_ld(&ctl->abort))) {
+					IO_FAIL(bi);
+					break;
 				}
+				IO_STAMP_ADD(9, 1);
 				__builtin_amdgcn_s_sleep(4);
 			}
 			/* every LDS read of this block has returned (its data went into the stores above) */
@@ -493,8 +752,10 @@ __global__ __launch_bounds__(IO_THREADS) void lz4_expand_inorder_kernel(
 			if (lane == 0)
 				io_st(&ctl->flushed, seqno);
 		}
+		IO_STAMP_FLUSH();
 	}
 #undef IO_LOAD_BLK
+#undef IO_FAIL
 }
 
 #ifdef LA_DIAG
@@ -504,6 +765,10 @@ extern "C" int la_diag_set_io_stamps(void *d_buf)
 	return (int)hipMemcpyToSymbol(HIP_SYMBOL(la_diag_io_stamps), &p, sizeof(p));
 }
 #endif
+
+/* the kernel's payload loads are pulled back from the end of the image by up to 16 bytes: images shorter than
+ * that go to the previous-generation kernel (the caller's choice, la_api.hip) */
+bool la_lz4_expand_inorder_takes(uint64_t src_bytes) { return src_bytes >= 16; }
 
 void la_launch_lz4_expand_inorder(hipStream_t s, const uint8_t *d_src, uint64_t src_bytes,
     const la_lz4_block *d_blocks, uint32_t n, uint8_t *d_dst, uint64_t dst_cap,
