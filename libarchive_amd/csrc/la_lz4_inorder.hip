@@ -45,16 +45,16 @@
 #define IO_BPW 8u		/* consecutive blocks one workgroup takes */
 #endif
 #ifndef IO_LWAVES
-#define IO_LWAVES 6u		/* literal waves per workgroup */
+#define IO_LWAVES 14u		/* literal waves per workgroup */
 #endif
-/* M + L waves + F work; the workgroup is launched with eight waves all the same (the rest leave at once): with two
- * workgroups of SIX waves per CU the compiler derives "3 waves per SIMD" from the LDS size and pads the register
- * allocation to 129 so that no fourth wave fits -- and then the second workgroup's 2+2+1+1 waves do not fit beside
- * the first's (measured: one workgroup per CU).  Eight waves per workgroup make it 4 per SIMD, 2 per SIMD and group. */
-#define IO_THREADS 512u
+/* M + IO_LWAVES L waves + F = sixteen waves, two workgroups per CU = the CU's 32 wave slots (64 VGPRs each).
+ * (A workgroup of SIX waves does not work: the compiler derives "3 waves per SIMD" from the LDS size, pads the
+ * register allocation to 129 so that no fourth wave fits, and then the second workgroup's 2+2+1+1 waves do not fit
+ * beside the first's -- measured: one workgroup per CU.) */
+#define IO_THREADS (64u * (IO_LWAVES + 2u))
 #define IO_SPIN_LIMIT (1u << 22)
 #ifndef IO_RING
-#define IO_RING 8u		/* groups of 64 sequence records L may be ahead of M */
+#define IO_RING 4u		/* groups of 64 sequences L may be ahead of M (records and literal stores) */
 #endif
 
 struct io_ctl {
@@ -296,6 +296,59 @@ __device__ __forceinline__ void io_copy_fast(const uint64_t R, const io_cls &K, 
 }
 #undef IO_DS
 
+/* The few matches of a group that the straight-line pass does not take -- a source that reaches into a match of the
+ * same group, more than 64 bytes, a source that overlaps the destination -- are copied one after the other by the
+ * WHOLE wave (everything about them is wave-uniform: v_readlane): a lone wave issues a DS instruction every 15 to
+ * 30 cycles whatever the number of lanes it enables, so a pass of sixteen predicated DS instructions for three
+ * lanes costs as much as for sixty; one read and one write for one match cost a tenth of that.  Taken in stream
+ * order they need no readiness test at all: the LDS executes this wave's instructions in order. */
+__device__ __forceinline__ void io_coop_copy(uint8_t *d, const uint8_t *s, uint32_t n, uint32_t lane)
+{
+	/* n bytes, ranges do not overlap; d, s, n wave-uniform */
+	if (n <= 64) {
+		if (lane < n) {
+			const uint8_t b = s[lane];
+			asm volatile("" ::: "memory");
+			d[lane] = b;
+		}
+		return;
+	}
+	uint32_t base = 0;
+	for (; base + 1024 <= n; base += 1024) {
+		const uint4 v = lds_ld16(s + base + 16 * lane);
+		asm volatile("" ::: "memory");
+		lds_st16(d + base + 16 * lane, v);
+	}
+	const uint32_t rem = n - base, nfull = rem >> 4, t0 = base + (nfull << 4), tail = rem & 15u;
+	uint4 v = make_uint4(0, 0, 0, 0);
+	uint8_t b = 0;
+	if (lane < nfull)
+		v = lds_ld16(s + base + 16 * lane);
+	if (lane < tail)
+		b = s[t0 + lane];
+	asm volatile("" ::: "memory");
+	if (lane < nfull)
+		lds_st16(d + base + 16 * lane, v);
+	if (lane < tail)
+		d[t0 + lane] = b;
+}
+
+/* one match, all arguments wave-uniform.  A match that overlaps its source (off < mlen) is a periodic run: the
+ * valid stretch behind the source doubles with every step (io_copy_match has the same scheme per lane). */
+__device__ __forceinline__ void io_coop_match(uint8_t *mp, uint32_t off, uint32_t mlen, uint32_t lane)
+{
+	const uint8_t *fp = mp - off;
+	uint32_t done = 0;
+	do {
+		uint32_t nn = off + done;
+		if (nn > mlen - done)
+			nn = mlen - done;
+		io_coop_copy(mp + done, fp, nn, lane);
+		asm volatile("" ::: "memory");
+		done += nn;
+	} while (done < mlen);
+}
+
 /* v >> (8 * bytes) over 128 bits, bytes >= 16 gives zeros (only the last 16 bytes of an image need it) */
 __device__ __forceinline__ uint4 io_shr128(uint4 v, uint32_t bytes)
 {
@@ -339,7 +392,7 @@ __device__ __forceinline__ void io_lit_store(uint8_t *d, const uint4 p0, const u
 	}
 }
 
-__global__ __launch_bounds__(IO_THREADS, 4) void lz4_expand_inorder_kernel(
+__global__ __launch_bounds__(IO_THREADS, 8) void lz4_expand_inorder_kernel(
     const uint8_t *__restrict__ src, uint64_t src_bytes, const la_lz4_block *__restrict__ blocks,
     uint32_t n, uint8_t *__restrict__ dst, uint64_t dst_cap, const uint64_t *__restrict__ dst_off,
     const uint32_t *__restrict__ out_len, uint32_t *status_out,
@@ -350,8 +403,7 @@ __global__ __launch_bounds__(IO_THREADS, 4) void lz4_expand_inorder_kernel(
 	/* 16 bytes of headroom + up to 15 of alignment shift + the window + slack for over-reads */
 	__shared__ __attribute__((aligned(16))) uint8_t win[16 + 16 + 65536 + 96];
 	/* what L has worked out for M, one 16-byte record per sequence, IO_RING groups deep:
-	 *   x = match destination (17 bits) | first << 17 | last << 23 | dep << 29: the lanes first..last of the group
-	 *       are the ones whose matches the source of this match overlaps (dep = 0: none);
+	 *   x = match destination (17 bits) | dep << 29 (the source reaches into the matches of the same group);
 	 *   y = match length, z = match offset, w = running number of the group + 1 -- the tag that tells M the
 	 *       record is there: a group's records are written by ONE ds_write_b128, after its literals. */
 	__shared__ __attribute__((aligned(16))) uint4 ring[IO_RING][64];
@@ -390,7 +442,9 @@ __global__ __launch_bounds__(IO_THREADS, 4) void lz4_expand_inorder_kernel(
 
 	if (wave == 0) {
 		/* ================= M: matches, in stream order ================= */
+#ifndef IO_NO_SETPRIO
 		__builtin_amdgcn_s_setprio(3);
+#endif
 #ifdef LA_DIAG
 		io_acc[12] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -427,21 +481,13 @@ __global__ __launch_bounds__(IO_THREADS, 4) void lz4_expand_inorder_kernel(
 				if (dead)
 					x = make_uint4(0, 0, 0, 0);	/* nothing to copy */
 				IO_STAMP_ADD(1, IO_NOW() - t_w0);
+				if (g == 0)
+					IO_STAMP_ADD(14, IO_NOW() - t_w0);
 				asm volatile("" ::: "memory");
 				const uint32_t mdst = x.x & 0x1FFFFu, mlen = x.y, off = x.z;
-				const uint32_t d_lo = (x.x >> 17) & 63u, d_hi = (x.x >> 23) & 63u;
-				const bool dep = (x.x >> 29) & 1u;
-				/* the lanes this one has to wait for, as a mask */
-#ifdef IO_DBG_NODEP	/* every lower lane counts as a dependency */
-				const uint64_t rmask = (1ull << lane) - 1ull;
-				(void)dep; (void)d_hi; (void)d_lo;
-#else
-				const uint64_t rmask = dep ? (2ull << d_hi) - (1ull << d_lo) : 0ull;
-#endif
-				bool fin = mlen == 0;
-				uint8_t *const mp = W + mdst;
+				const bool dep = (x.x >> 29) & 1u;	/* the source reaches into the matches of this group */
 				const bool slow = mlen > 64 || off < mlen;
-				const uint32_t mf = (mlen != 0 && !slow) ? mlen : 0u;	/* length if the straight-line copy takes the match */
+				const uint32_t mf = (mlen != 0 && !slow && !dep) ? mlen : 0u;	/* length if the straight-line pass takes the match */
 				io_cls K;
 				K.k16 = __ballot(mf >= 16);
 				K.k32 = __ballot(mf >= 32);
@@ -454,7 +500,7 @@ __global__ __launch_bounds__(IO_THREADS, 4) void lz4_expand_inorder_kernel(
 				K.ks44 = __ballot(mf > 4 && mf < 8);
 				K.k2 = __ballot(mf != 0 && mf < 4 && (mf & 2));
 				K.k1 = __ballot(mf != 0 && mf < 4 && (mf & 1));
-				const uint64_t kslow = __ballot(slow && mlen != 0);
+				uint64_t Q = __ballot(mlen != 0 && (slow || dep));	/* the matches taken one by one afterwards */
 				io_adr A;
 				A.mp = w_lds + mdst;
 				A.fp = A.mp - off;
@@ -473,36 +519,29 @@ __global__ __launch_bounds__(IO_THREADS, 4) void lz4_expand_inorder_kernel(
 				[[maybe_unused]] const unsigned long long t_p0 = IO_NOW();
 				[[maybe_unused]] unsigned long long t_p1 = t_p0;
 
-				/* pass 1: every match whose source does not reach into a match of its own group.  Then rounds:
-				 * a lane is ready when none of the lanes it waits for is unfinished (the lowest unfinished
-				 * lane always is) */
-				uint64_t unf = __ballot(!fin);
-				uint32_t rounds = 0;
-				while (unf) {
-					const bool ready = !fin && (rmask & unf) == 0;
-					const uint64_t R = __ballot(ready);
+				/* the straight-line pass: every match of at most 64 bytes that neither overlaps its source nor reaches
+				 * into the matches of its own group (about nineteen in twenty on the C2 stream) ... */
 #ifndef IO_EXP_NO_COPY	/* timing experiment */
-					io_copy_fast(R, K, A);
+				io_copy_fast(K.ks | K.k16, K, A);
 #endif
-					if (R & kslow) {	/* longer than 64 bytes or overlapping its source: rare */
-						if (ready && slow)
-							io_copy_match(mp, off, mlen);
-					}
-					fin = fin || ready;
-					asm volatile("" ::: "memory");
 #ifdef LA_DIAG
-					if (rounds == 0) t_p1 = IO_NOW();
+				t_p1 = IO_NOW();
 #endif
-#ifdef IO_EXP_NO_LATE	/* timing experiment: one pass only (wrong output) */
-					break;
-#endif
-					unf &= ~R;
-					if (R == 0 || ++rounds > 64u) {	/* cannot happen: the lowest unfinished lane is always ready */
-						IO_FAIL(bi);
-						break;
-					}
+				/* ... then the others in stream order, each by the whole wave */
+				uint32_t nq = 0;
+#ifndef IO_EXP_NO_LATE	/* timing experiment (wrong output) */
+				while (Q) {
+					const uint32_t qi = (uint32_t)__builtin_ctzll(Q);
+					Q &= Q - 1;
+					const uint32_t q_md = (uint32_t)__builtin_amdgcn_readlane((int)mdst, (int)qi);
+					const uint32_t q_off = (uint32_t)__builtin_amdgcn_readlane((int)off, (int)qi);
+					const uint32_t q_ml = (uint32_t)__builtin_amdgcn_readlane((int)mlen, (int)qi);
+					io_coop_match(W + q_md, q_off, q_ml, lane);
+					nq++;
 				}
-				IO_STAMP_ADD(2, rounds);
+#endif
+				asm volatile("" ::: "memory");
+				IO_STAMP_ADD(2, nq);
 #ifdef LA_DIAG
 				IO_STAMP_ADD(6, t_p1 - t_p0);
 				IO_STAMP_ADD(7, IO_NOW() - t_p1);
@@ -584,6 +623,10 @@ __global__ __launch_bounds__(IO_THREADS, 4) void lz4_expand_inorder_kernel(
 				uint4 pB0, pBt;
 				uint32_t shB0, shBt;
 				IO_LOAD_P(pB0, pBt, shB0, shBt, eB);
+#ifdef LA_DIAG
+				if (g == g0 && g == 0)
+					IO_STAMP_ADD(4, IO_NOW() - t_l0);	/* loads of the iteration issued */
+#endif
 				/* this group */
 				const seq_t e = eA;
 				const uint32_t k = g * 64 + lane;
@@ -607,6 +650,13 @@ __global__ __launch_bounds__(IO_THREADS, 4) void lz4_expand_inorder_kernel(
 				if (dead)
 					ll = 0;		/* (mdst stays as computed: only consistent positions are handed on) */
 				const uint32_t G = gbase + g;
+				/* L works at most IO_RING groups ahead of M: the ring slot is free when M is done with the group IO_RING
+				 * places back -- and the literal stores of the groups M needs first are not queued behind those of groups it
+				 * needs much later (when a window is handed back every literal wave has a group ready to store) */
+				[[maybe_unused]] const unsigned long long t_r0 = IO_NOW();
+				if (G >= IO_RING && !io_wait_ge(&ctl->match_groups, G + 1 - IO_RING, ctl, 1))
+					IO_FAIL(bi);
+				IO_STAMP_ADD(11, IO_NOW() - t_r0);
 #ifdef IO_EXP_NO_LIT	/* timing experiment: no literal stores (wrong output) */
 				if (ll > 0x100000u) {
 #else
@@ -639,35 +689,27 @@ __global__ __launch_bounds__(IO_THREADS, 4) void lz4_expand_inorder_kernel(
 							lds_st16(wd + ll - 16, ld_u128(s + ls + ll - 16));
 					}
 				}
-				/* Which matches of this group does the source of each match overlap?  The matches of the group lie in
-				 * stream order: [bm, em) of lane i ends before lane i + 1's begins.  The source [s0, send) (send: the
-				 * end of the part that exists before the copy starts) meets the lanes first .. last with
-				 * first = #{i: em_i <= s0}, last = #{i: bm_i < send} - 1: two binary searches over the lanes
-				 * (ds_bpermute), run side by side.  Both counts are below this lane's own number. */
-				const uint32_t bm = valid ? mdst : olen, em = bm + mlen;
+#ifdef LA_DIAG
+				if (g == g0 && g == 0)
+					IO_STAMP_ADD(9, IO_NOW() - t_l0);	/* literals stored */
+#endif
+				/* Does the source of the match reach into the matches of its own group (it ends behind the start of the
+				 * group's first match)?  Then M takes it after the straight-line pass, in stream order. */
+				const uint32_t bm = valid ? mdst : olen;
 				const uint32_t s0 = bm - off, send = s0 + (mlen < off ? mlen : off);
-				uint32_t cl = 0, ch = 0;
-#pragma unroll
-				for (uint32_t step = 32; step; step >>= 1) {
-					const uint32_t ve = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((cl + step - 1) << 2), (int)em);
-					const uint32_t vb = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((ch + step - 1) << 2), (int)bm);
-					if (ve <= s0) cl += step;
-					if (vb < send) ch += step;
-				}
-				const bool dep = mlen != 0 && cl < ch;	/* first = cl <= last = ch - 1 */
-				/* the ring slot is free when M is done with the group IO_RING places back */
-				[[maybe_unused]] const unsigned long long t_r0 = IO_NOW();
-				if (G >= IO_RING && !io_wait_ge(&ctl->match_groups, G + 1 - IO_RING, ctl, 1))
-					IO_FAIL(bi);
-				IO_STAMP_ADD(11, IO_NOW() - t_r0);
+				const bool dep = mlen != 0 && send > (uint32_t)__builtin_amdgcn_readfirstlane((int)bm);
 				/* the records go out last, in one instruction: their tag tells M that the group's literals are in
 				 * the window too (the LDS runs a wave's instructions in order) */
 #ifdef IO_DBG_LWAIT
 				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
 				asm volatile("" ::: "memory");
-				ring[G % IO_RING][lane] = make_uint4(bm | (dep ? (cl << 17) | ((ch - 1) << 23) | (1u << 29) : 0u), mlen, valid ? off : 0u, G + 1);
+				ring[G % IO_RING][lane] = make_uint4(bm | (dep ? 1u << 29 : 0u), mlen, valid ? off : 0u, G + 1);
 				asm volatile("" ::: "memory");
+#ifdef LA_DIAG
+				if (g == g0 && g == 0)	/* the wave that writes a block's first records: window free -> records out */
+					IO_STAMP_ADD(10, IO_NOW() - t_l0);
+#endif
 				eA = eB; nA = nB;
 				eB = eC; nB = nC;
 				pA0 = pB0; pAt = pBt; shA0 = shB0; shAt = shBt;
@@ -730,11 +772,13 @@ __global__ __launch_bounds__(IO_THREADS, 4) void lz4_expand_inorder_kernel(
 					moved = true;
 				}
 				if (complete) {
+					[[maybe_unused]] const unsigned long long t_f0 = IO_NOW();
 					if (lane < head)
 						g_out[lane] = W[lane];
 					const uint32_t tail0 = head + (nunits << 4);
 					if (tail0 + lane < olen)
 						g_out[tail0 + lane] = W[tail0 + lane];
+					IO_STAMP_ADD(15, IO_NOW() - t_f0);
 					break;
 				}
 				if (moved) {
@@ -743,7 +787,6 @@ __global__ __launch_bounds__(IO_THREADS, 4) void lz4_expand_inorder_kernel(
 					IO_FAIL(bi);
 					break;
 				}
-				IO_STAMP_ADD(9, 1);
 				__builtin_amdgcn_s_sleep(4);
 			}
 			/* every LDS read of this block has returned (its data went into the stores above) */

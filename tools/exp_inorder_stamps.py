@@ -34,7 +34,7 @@ print("M: cycles per block %.0f = per group %.0f; waiting for L %.0f per group; 
       (tot[0] / blocks, tot[0] / groups, tot[1] / groups, tot[2] / groups))
 print("M: pass 1 %.0f cycles per group, later rounds %.0f per group" % (tot[6] / groups, tot[7] / groups))
 print("M: the rest (ring read, unpack, publish) %.0f per group" % ((tot[0] - tot[1] - tot[6] - tot[7]) / groups))
-lw = int(os.environ.get("IO_LWAVES", "6"))
+lw = int(os.environ.get("IO_LWAVES", "14"))
 print("L (%d waves): %.0f cycles per block and wave in the group loop (%.0f per group of the wave), waiting for the window %.0f per block and wave" %
       (lw, tot[8] / blocks / lw, tot[8] / groups, tot[5] / blocks / lw))
 print("L: waiting for a ring slot (for M) %.0f cycles per group of the wave; F: %.1f polls per block" % (tot[11] / groups, tot[9] / blocks))
@@ -43,3 +43,8 @@ ok = t0 > 0
 span = (t1[ok].max() - t0[ok].min())
 print("workgroups in flight on average: %.1f (sum of lifetimes %.0f / span %.0f ticks of 10 ns); mean lifetime %.1f us, span %.1f us" %
       ((t1[ok] - t0[ok]).sum() / span, (t1[ok] - t0[ok]).sum(), span, (t1[ok] - t0[ok]).mean() / 100, span / 100))
+if tot[4] and tot[14]:
+    print("LDS round trip seen by M (drained before and after): %.0f cycles at the head of pass 1, %.0f at the head of a later round" % (tot[14] / tot[4], tot[15] / max(tot[10], 1)))
+print("M: wait for the first records of a block %.0f cycles per block (of all waiting for L: %.0f per block); F: tail after the last group %.0f cycles per block" % (tot[14] / blocks, tot[1] / blocks, tot[15] / blocks))
+print("L: from the window being free to the block's first records %.0f cycles per block" % (tot[10] / blocks))
+print("L, first iteration of a block: loads issued after %.0f cycles, literals stored after %.0f, records out after %.0f" % (tot[4] / blocks, tot[9] / blocks, tot[10] / blocks))
