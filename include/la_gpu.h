@@ -178,9 +178,10 @@ typedef struct la_batch_summary {
 #define LA_LZ4_OPT_PARSE_V1     4u	/* first-generation parse: block checksums and token walk as two kernels
 					 * reading global memory per lane (kept as a cross-check of the staged one) */
 
-#define LA_LZ4_OPT_EXPAND_POLL  8u	/* previous generation of the LDS-window expand step (la_lz4_fast.hip: one thread per
-					 * sequence, matches poll per-sequence done bits); same results, kept as the cross-check of
-					 * the in-order kernel (la_lz4_inorder.hip), which is the default since ABI 3 */
+#define LA_LZ4_OPT_EXPAND_INORDER 8u	/* second implementation of the LDS-window expand step (la_lz4_inorder.hip, round 3: one
+					 * matcher wave takes the sequences in stream order, literal waves run ahead of it, a flush wave
+					 * behind it; no per-sequence flags, no polling in the match phase); same results, kept as the
+					 * cross-check of the default kernel (la_lz4_fast.hip), which is still the faster one */
 
 typedef struct la_lz4_batch {
 	const uint8_t      *d_src;	/* compressed image (or batch window) in HBM */
@@ -250,7 +251,7 @@ typedef struct la_gz_batch {
 #define LA_GZ_OPT_LANE_KERNEL 4u	/* force the in-place lane-per-member kernel */
 #define LA_GZ_OPT_TWO_PHASE   8u	/* force entropy decode + LDS-window expand (the default from 8192 members up) */
 
-#define LA_GZ_OPT_EXPAND_POLL 32u	/* two-phase path: build the output with the previous-generation expand kernel (cross-check) */
+#define LA_GZ_OPT_EXPAND_INORDER 32u	/* two-phase path: build the output with the in-order expand kernel (cross-check) */
 #define LA_GZ_OPT_RAW        16u	/* members are bare raw-deflate streams (ZIP entries, archive_read_support_format_zip.c:2536-2700):
 					 * no gzip trailer follows the body, nothing is compared; status, out_len, consumed and
 					 * the CRC32 of the produced bytes are reported */

@@ -32,7 +32,7 @@ assert HASH_JOB_DTYPE.itemsize == 16 and SUMMARY_DTYPE.itemsize == 32
 
 LA_LZ4B_STORED, LA_LZ4B_CHECKSUM, LA_LZ4B_DEPENDENT, LA_LZ4B_FIRST = 1, 2, 4, 8
 LA_LZ4F_CONTENT_SUM, LA_LZ4F_HEADER_SUM, LA_LZ4F_CONT, LA_LZ4F_OPEN, LA_LZ4F_HASHED = 1, 2, 4, 8, 16
-LA_LZ4_OPT_GENERAL_ONLY, LA_LZ4_OPT_NO_VERIFY, LA_LZ4_OPT_PARSE_V1, LA_LZ4_OPT_EXPAND_POLL = 1, 2, 4, 8
+LA_LZ4_OPT_GENERAL_ONLY, LA_LZ4_OPT_NO_VERIFY, LA_LZ4_OPT_PARSE_V1, LA_LZ4_OPT_EXPAND_INORDER = 1, 2, 4, 8
 LA_GPU_ABI_VERSION = 3
 
 (LA_END_EOF, LA_END_TRUNCATED, LA_END_MALFORMED, LA_END_MALFORMED_SKIP, LA_END_EMPTY_FRAME,

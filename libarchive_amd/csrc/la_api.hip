@@ -341,8 +341,8 @@ int la_gpu_lz4_decode(la_gpu_ctx *c, const la_lz4_batch *bt)
 		return LA_ERR_ARG;
 	const bool fast = !(bt->options & LA_LZ4_OPT_GENERAL_ONLY);
 	const bool verify = !(bt->options & LA_LZ4_OPT_NO_VERIFY);
-	/* previous-generation expand kernel: on request (cross-check), and for images of less than 16 bytes */
-	const bool poll = (bt->options & LA_LZ4_OPT_EXPAND_POLL) != 0 || !la_lz4_expand_inorder_takes(bt->src_bytes);
+	/* the in-order expand kernel runs on request (cross-check); not for images of less than 16 bytes */
+	const bool poll = (bt->options & LA_LZ4_OPT_EXPAND_INORDER) == 0 || !la_lz4_expand_inorder_takes(bt->src_bytes);
 	lz4_ws w;
 	lz4_ws_layout(&w, NULL, bt->n_blocks, bt->src_bytes, fast);
 	if (w.total > c->ws_bytes) {
@@ -407,9 +407,8 @@ int la_gpu_lz4_decode(la_gpu_ctx *c, const la_lz4_batch *bt)
 	    bt->hist_len, LA_LZ4_LONG_SEQ_BYTES);	/* ... except blocks of few long sequences (la_dev.h) */
 	prof_close(c, h, sx);
 	if (fast && poll) {
-		/* eligible blocks with more sequences than one LDS segment of the polling kernel: classified on the
-		 * device, shared out over a small grid (a no-op launch when there are none).  The in-order kernel
-		 * takes blocks of any sequence count. */
+		/* eligible blocks with more sequences than one LDS segment: classified on the device, shared out over a
+		 * small grid (a no-op launch when there are none).  (The in-order kernel takes blocks of any sequence count.) */
 		h = prof_open(c, "lz4_expand_big", sx);
 		la_launch_lz4_expand_fast_big(sx, bt->d_src, bt->src_bytes, bt->d_blocks, n, bt->d_dst, bt->dst_cap,
 		    bt->d_dst_off, bt->d_out_len, bt->d_block_status, w.nseq, w.table, w.table_off, w.big, LA_LZ4_LONG_SEQ_BYTES);
@@ -540,7 +539,7 @@ int la_gpu_gzip_decode(la_gpu_ctx *c, const la_gz_batch *bt)
 		la_launch_inflate_symbols(s, bt->d_src, bt->src_bytes, bt->d_members, n, bt->dst_cap, bt->d_results, wsb, E);
 		prof_close(c, h, s);
 		h = prof_open(c, "inflate_expand", s);
-		if (bt->options & LA_GZ_OPT_EXPAND_POLL) {
+		if (!(bt->options & LA_GZ_OPT_EXPAND_INORDER)) {
 			la_launch_lz4_expand_fast(s, E.lit, (uint64_t)n * 65536u, E.blocks, n, bt->d_dst, bt->dst_cap,
 			    E.dst_off, E.out_len, E.xstatus, E.nseq, E.table, E.table_off, 0u);
 			/* members with more matches than one LDS segment of the polling kernel holds */

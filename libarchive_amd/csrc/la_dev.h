@@ -333,6 +333,88 @@ __device__ __forceinline__ uint64_t lds_ld_tail(const uint8_t *p, uint32_t n)
 	return v;
 }
 
+/* The usual match -- at most 64 bytes, not overlapping its source -- as ONE straight line of predicated DS
+ * instructions.  A wave on its own issues an instruction every four or five cycles and pays an instruction-fetch
+ * restart for every taken branch, and the matcher's passes are nothing but this copy: what the compiler makes of
+ * `if (class) copy piece` is three to eight instructions and up to two branches per piece.  Here a piece is two:
+ * exec = ready lanes of the class (both wave-uniform masks, the class masks worked out once per group), then the
+ * DS instruction; no branch.  All loads are issued before anything is stored, pieces as in io_copy_exact:
+ * 16-byte pieces at 0 / 16 / 32 and one that ENDS with the match, 8 + 8 overlapping below 16 bytes, 4 + 4 below 8,
+ * 2 + 1 below 4 (1..3 bytes: only the deflate front end makes these). */
+typedef uint32_t io_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t io_u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) uint8_t io_lds_u8;
+__device__ __forceinline__ uint32_t io_lds_addr(const uint8_t *p) { return (uint32_t)(uintptr_t)(const io_lds_u8 *)p; }
+
+struct io_cls {		/* lanes of the group by length class, fast lanes only (wave-uniform, one SGPR pair each) */
+	uint64_t k16, k32, k48, ke;	/* >= 16, >= 32, >= 48, end piece (length > 16 and not 32 or 48) */
+	uint64_t ks, ks8, ks88;		/* < 16 (8-byte load), 8..15, 9..15 */
+	uint64_t ks4, ks44, k2, k1;	/* 4..7, 5..7, {2,3}, {1,3} */
+};
+struct io_adr {		/* per lane: LDS byte addresses and shift counts */
+	uint32_t fp, mp;	/* source, destination */
+	uint32_t fe, me;	/* + length - 16 */
+	uint32_t f8, m8;	/* + length - 8 */
+	uint32_t m4, sh4;	/* mp + length - 4, 8 * (length - 4) */
+	uint32_t m1, sh1;	/* mp + (length & 2), 8 * (length & 2) */
+};
+
+/* one predicated DS instruction: exec = ready lanes of the class, then the instruction (IO_EXP_SKIP_EMPTY: the
+ * instruction is jumped over when no lane is left -- a timing experiment, see profiles/r03_inorder_whatif.txt) */
+#ifdef IO_EXP_SKIP_EMPTY
+#define IO_DS(mask_, ins_, n_) "s_and_b64 exec, %[R], %[" mask_ "]\n\ts_cbranch_execz .Lio" n_ "_%=\n\t" ins_ "\n\t.Lio" n_ "_%=:\n\t"
+#else
+#define IO_DS(mask_, ins_, n_) "s_and_b64 exec, %[R], %[" mask_ "]\n\t" ins_ "\n\t"
+#endif
+__device__ __forceinline__ void io_copy_fast(const uint64_t R, const io_cls &K, const io_adr &A)
+{
+	io_u32x4 v0, v1, v2, vt;
+	io_u32x2 a0, at;
+	uint64_t sv;
+	asm volatile(
+	    "s_mov_b64 %[sv], exec\n\t"
+	    IO_DS("k16", "ds_read_b128 %[v0], %[fp]", "0")
+	    IO_DS("k32", "ds_read_b128 %[v1], %[fp] offset:16", "1")
+	    IO_DS("k48", "ds_read_b128 %[v2], %[fp] offset:32", "2")
+	    IO_DS("ke", "ds_read_b128 %[vt], %[fe]", "3")
+	    IO_DS("ks", "ds_read_b64 %[a0], %[fp]", "4")
+	    IO_DS("ks88", "ds_read_b64 %[at], %[f8]", "5")
+	    "s_mov_b64 exec, %[sv]\n\t"
+	    "s_waitcnt lgkmcnt(0)"
+	    : [sv] "=&s"(sv), [v0] "=&v"(v0), [v1] "=&v"(v1), [v2] "=&v"(v2), [vt] "=&v"(vt), [a0] "=&v"(a0), [at] "=&v"(at)
+	    : [R] "s"(R), [k16] "s"(K.k16), [k32] "s"(K.k32), [k48] "s"(K.k48), [ke] "s"(K.ke), [ks] "s"(K.ks), [ks88] "s"(K.ks88),
+	      [fp] "v"(A.fp), [fe] "v"(A.fe), [f8] "v"(A.f8)
+	    : "memory");
+	/* (lanes outside a class hold garbage in that class's registers: never stored) */
+#ifdef IO_EXP_LOADS_ONLY	/* timing experiment */
+	asm volatile("" :: "v"(v0), "v"(v1), "v"(v2), "v"(vt), "v"(a0), "v"(at));
+	return;
+#endif
+	const uint32_t a0lo = a0.x;
+	const uint32_t t4 = (uint32_t)((((uint64_t)a0.y << 32) | a0.x) >> (A.sh4 & 63u));
+	const uint32_t t1 = a0lo >> (A.sh1 & 31u);
+	asm volatile(
+	    "s_mov_b64 %[sv], exec\n\t"
+	    IO_DS("k16", "ds_write_b128 %[mp], %[v0]", "0")
+	    IO_DS("k32", "ds_write_b128 %[mp], %[v1] offset:16", "1")
+	    IO_DS("k48", "ds_write_b128 %[mp], %[v2] offset:32", "2")
+	    IO_DS("ke", "ds_write_b128 %[me], %[vt]", "3")
+	    IO_DS("ks8", "ds_write_b64 %[mp], %[a0]", "4")
+	    IO_DS("ks88", "ds_write_b64 %[m8], %[at]", "5")
+	    IO_DS("ks4", "ds_write_b32 %[mp], %[a0lo]", "6")
+	    IO_DS("ks44", "ds_write_b32 %[m4], %[t4]", "7")
+	    IO_DS("k2", "ds_write_b16 %[mp], %[a0lo]", "8")
+	    IO_DS("k1", "ds_write_b8 %[m1], %[t1]", "9")
+	    "s_mov_b64 exec, %[sv]"
+	    : [sv] "=&s"(sv)
+	    : [R] "s"(R), [k16] "s"(K.k16), [k32] "s"(K.k32), [k48] "s"(K.k48), [ke] "s"(K.ke), [ks8] "s"(K.ks8), [ks88] "s"(K.ks88),
+	      [ks4] "s"(K.ks4), [ks44] "s"(K.ks44), [k2] "s"(K.k2), [k1] "s"(K.k1),
+	      [mp] "v"(A.mp), [me] "v"(A.me), [m8] "v"(A.m8), [m4] "v"(A.m4), [m1] "v"(A.m1),
+	      [v0] "v"(v0), [v1] "v"(v1), [v2] "v"(v2), [vt] "v"(vt), [a0] "v"(a0), [at] "v"(at), [a0lo] "v"(a0lo), [t4] "v"(t4), [t1] "v"(t1)
+	    : "memory");
+}
+#undef IO_DS
+
 /* ---- launch interface (definitions live next to their kernels) ---- */
 
 /* la_hash.hip */

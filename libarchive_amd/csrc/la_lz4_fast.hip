@@ -490,7 +490,7 @@ __global__ __launch_bounds__(FAST_THREADS, FAST_MIN_WAVES) void lz4_expand_fast_
 							for (uint32_t i = 0;; i += 32) {	/* one trip up to 47 bytes */
 								const uint32_t left = mlen - i;
 								const uint4 v0 = lds_ld16(fp + i);
-								uint4 v1 = v0, vt = v0;
+								uint4 v1 = make_uint4(0, 0, 0, 0), vt = make_uint4(0, 0, 0, 0);	/* (not from v0: nothing makes one DS read wait for another) */
 								if (left >= 32)
 									v1 = lds_ld16(fp + i + 16);
 								const bool last = left < 48;	/* 16..47 bytes left: this trip ends the match */

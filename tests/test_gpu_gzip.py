@@ -15,16 +15,16 @@ ST_OK, ST_DATA, ST_TRUNC, ST_BAD_CRC, ST_BAD_ISIZE, ST_FULL, ST_NOTRAILER = 0, 5
 
 def gpu_inflate(ctx, bodies, caps, verify=True):
     """Runs ALL deflate paths (wave per member; lane per member in place; lane per member
-    entropy decode + in-order LDS-window expand with the in-place kernel as its fallback; the
-    same with the previous-generation polling expand kernel) and insists they agree."""
+    entropy decode + LDS-window expand with the in-place kernel as its fallback; the same with
+    the in-order expand kernel of round 3) and insists they agree."""
     a, sa = _gpu_inflate(ctx, bodies, caps, verify, 2)
     # `consumed` only means something when the deflate stream ended (status OK / trailer verdicts)
     # (and a member that does not fit its slot is never delivered -- the filter retries it with a larger
     # slot -- so how many bytes a kernel had produced when it noticed is not part of the contract)
     norm = lambda rs: [(st, None, None, None) if st == ST_FULL else
                        (st, out, cons if st in (ST_OK, ST_BAD_CRC, ST_BAD_ISIZE, ST_NOTRAILER) else None, crc) for st, out, cons, crc in rs]
-    for opt, what in ((4, "lane-per-member in-place"), (8, "two-phase (entropy decode + in-order LDS-window expand)"),
-                      (8 | 32, "two-phase (entropy decode + polling LDS-window expand)")):
+    for opt, what in ((4, "lane-per-member in-place"), (8, "two-phase (entropy decode + LDS-window expand)"),
+                      (8 | 32, "two-phase (entropy decode + in-order LDS-window expand)")):
         b, sb = _gpu_inflate(ctx, bodies, caps, verify, opt)
         assert norm(a) == norm(b), "wave-per-member and %s kernels disagree" % what
         assert int(sa["n_bad_units"]) == int(sb["n_bad_units"])

@@ -17,18 +17,18 @@ MANIFEST = [e for e in json.load(open(os.path.join(GOLD, "manifest.json"))) if e
 
 
 def gpu_decode(ctx, image, options=None):
-    """Runs ALL THREE expand paths (in-order LDS-window kernel + general kernel, general kernel only,
-    previous-generation polling LDS-window kernel) and BOTH parse generations (LDS-staged fused parse+checksum, and the two first-generation
+    """Runs ALL THREE expand paths (LDS-window kernel + general kernel, general kernel only, the in-order
+    LDS-window kernel of round 3) and BOTH parse generations (LDS-staged fused parse+checksum, and the two first-generation
     kernels) and insists that all of them agree before returning the result."""
     from libarchive_amd.lz4 import decode_image
     from libarchive_amd import _native as N
     res = []
     for opt in ((0, N.LA_LZ4_OPT_GENERAL_ONLY, N.LA_LZ4_OPT_PARSE_V1,
                  N.LA_LZ4_OPT_PARSE_V1 | N.LA_LZ4_OPT_GENERAL_ONLY,
-                 N.LA_LZ4_OPT_EXPAND_POLL) if options is None else (options,)):
+                 N.LA_LZ4_OPT_EXPAND_INORDER) if options is None else (options,)):
         out, rc, msg, plan = decode_image(ctx, image, options=opt)
         res.append((out.tobytes(), rc, msg))
-    assert all(r == res[0] for r in res), "kernel variants disagree (expand in-order/general/polling x parse staged/v1)"
+    assert all(r == res[0] for r in res), "kernel variants disagree (expand window/general/in-order x parse staged/v1)"
     return res[0]
 
 

@@ -34,7 +34,7 @@ print("M: cycles per block %.0f = per group %.0f; waiting for L %.0f per group; 
       (tot[0] / blocks, tot[0] / groups, tot[1] / groups, tot[2] / groups))
 print("M: pass 1 %.0f cycles per group, later rounds %.0f per group" % (tot[6] / groups, tot[7] / groups))
 print("M: the rest (ring read, unpack, publish) %.0f per group" % ((tot[0] - tot[1] - tot[6] - tot[7]) / groups))
-lw = int(os.environ.get("IO_LWAVES", "14"))
+lw = int(os.environ.get("IO_LWAVES", "6"))
 print("L (%d waves): %.0f cycles per block and wave in the group loop (%.0f per group of the wave), waiting for the window %.0f per block and wave" %
       (lw, tot[8] / blocks / lw, tot[8] / groups, tot[5] / blocks / lw))
 print("L: waiting for a ring slot (for M) %.0f cycles per group of the wave; F: %.1f polls per block" % (tot[11] / groups, tot[9] / blocks))

@@ -11,7 +11,7 @@ for name, blk in (("zeros", bytes(65536)), ("period7", (b"abcdefg" * 9400)[:6553
     img = np.frombuffer(img * 256, dtype=np.uint8)     # 4096 blocks = 256 MiB decoded
     idx = la.lz4_index(img)
     plan = Lz4DevicePlan(ctx, torch.from_numpy(img.copy()).cuda(), idx)
-    for opt, tag in ((0, "default"), (N.LA_LZ4_OPT_EXPAND_POLL, "polling"), (N.LA_LZ4_OPT_GENERAL_ONLY, "general")):
+    for opt, tag in ((0, "default"), (N.LA_LZ4_OPT_EXPAND_INORDER, "in-order"), (N.LA_LZ4_OPT_GENERAL_ONLY, "general")):
         plan.run(opt); ctx.sync()
         t0 = time.time(); plan.run(opt); ctx.sync(); dt = time.time() - t0
         sm = plan.summary()
