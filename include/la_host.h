@@ -100,6 +100,7 @@ size_t la_gz_header_parse(const uint8_t *p, size_t avail, la_gz_header *h);
 int    la_gz_bid_bytes(const uint8_t *p, size_t avail);
 /* Walk img[0..len): member table with per-member output slots (dst_off assigned back to
  * back from each member's ISIZE claim).  first_only: index just the first member. */
+uint64_t la_gz_span_limit(void);	/* 4 GiB - 1 (LA_GZ_TEST_SPAN_LIMIT lowers it for tests) */
 int    la_gz_index_build(const uint8_t *img, uint64_t len, int at_eof, la_gz_index *idx);
 /* first_skip: candidate boundaries to pass over for the first member (refuted by a decode);
  * first_cap: minimum output slot of the first member (its ISIZE claim proved too small) */
@@ -130,6 +131,16 @@ int la_zstd_bid_bytes(const uint8_t *p, size_t avail);
 /* Frame table of img[0..len): frame and block headers only.  out_budget as for the other walkers. */
 int la_zstd_index_build(const uint8_t *img, uint64_t len, int at_eof, uint64_t out_budget, la_zstd_frame *frames,
         uint32_t cap, la_zstd_index_result *res);
+
+/* ---- bid policy (host/la_bid_policy.c): does the stream hold many independent units, or ONE serial one that the
+ * reference's own filter decodes faster on a host core?  Used by the three bidders; LA_GPU_BID=all switches it off. ---- */
+struct archive_read_filter;
+int    la_bid_take_all(void);
+size_t la_bid_lookahead(size_t default_kib);
+const unsigned char *la_bid_peek(struct archive_read_filter *filter, size_t want, size_t *got);
+int    la_bid_gzip_parallel(const unsigned char *p, size_t n, size_t hdr_len, size_t lookahead);
+int    la_bid_lz4_parallel(const unsigned char *p, size_t n, size_t lookahead);
+int    la_bid_zstd_parallel(const unsigned char *p, size_t n, size_t lookahead);
 
 /* ---- hash drop-ins (host/la_hash_dropin.c) ----
  * The 4-pointer table of libarchive/archive_xxhash.h:37-46 (defined as `__archive_xxhash` when built

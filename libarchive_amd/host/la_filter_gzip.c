@@ -57,6 +57,7 @@ struct gzip_private {
 	uint32_t hint_skip, hint_cap;
 	uint64_t out_budget;	/* decoded bytes (output slots) one window may ask for: LA_GPU_OUT_BUDGET_MIB, default 4096 */
 	int strict;
+	uint32_t slot_limit;	/* an output slot cannot pass 2 GiB (32-bit positions on the device); LA_GZ_TEST_SLOT_LIMIT lowers it for tests */
 	int trace;
 	int loose;		/* the stream's headers carry unusual XFL / OS bytes: index without LA_GZ_INDEX_STRICT */
 	/* header metadata (gzip.c:280-296) */
@@ -132,6 +133,16 @@ static int gzip_bidder_bid(struct archive_read_filter_bidder *self, struct archi
 			const char *only = getenv("LA_GZIP_BID_ONLY_INDEXED");
 			if (only && only[0] == '1' && h.bgzf_size == 0)
 				return 0;
+			/* Default policy (la_bid_policy.c): ONE large member is a single serial deflate chain -- one wave on the
+			 * device, far slower than zlib on a host core -- so a stream whose first member carries no size subfield and
+			 * shows no second member header inside the look-ahead is not bid for (LA_GPU_BID=all takes everything). */
+			if (h.bgzf_size == 0 && !la_bid_take_all()) {
+				const size_t la = la_bid_lookahead(256);
+				size_t got = 0;
+				const unsigned char *w = la_bid_peek(filter, la, &got);
+				if (w != NULL && !la_bid_gzip_parallel(w, got, h.len, la))
+					return 0;
+			}
 			return 27;
 		}
 		p = __archive_read_filter_ahead(filter, (size_t)avail + 1, &avail);
@@ -159,6 +170,12 @@ static int gzip_bidder_init(struct archive_read_filter *self)
 	const char *dev = getenv("LA_GPU_DEVICE"), *bm = getenv("LA_GPU_BATCH_MIB"), *sv = getenv("LA_GZIP_STRICT");
 	st->batch_bytes = (size_t)(bm && atoi(bm) > 0 ? atoi(bm) : 256) << 20;
 	st->strict = sv && atoi(sv) != 0;
+	st->slot_limit = 0x80000000u;
+	{
+		const char *sl = getenv("LA_GZ_TEST_SLOT_LIMIT");
+		if (sl != NULL && strtoul(sl, NULL, 10) >= 65536 && strtoul(sl, NULL, 10) < st->slot_limit)
+			st->slot_limit = (uint32_t)strtoul(sl, NULL, 10);
+	}
 	const char *ob = getenv("LA_GPU_OUT_BUDGET_MIB");
 	st->out_budget = (uint64_t)(ob && atoi(ob) > 0 ? atoi(ob) : 4096) << 20;
 	st->trace = getenv("LA_GPU_TRACE") != NULL && atoi(getenv("LA_GPU_TRACE")) != 0;
@@ -316,7 +333,7 @@ static int gzip_run_batch(struct archive_read_filter *self, struct gzip_private 
 			/* the ISIZE claim was too small for what the member really holds */
 			*used = (size_t)member_start;
 			uint32_t base = m->dst_cap > prev_cap ? m->dst_cap : prev_cap;
-			if (base >= 0x80000000u) {
+			if (base >= st->slot_limit) {
 				/* the slot cannot grow any further (32-bit positions on the device): say so
 				 * instead of retrying for ever or delivering a wrapped slot */
 				gz_set_fatal(st, la_end_message(LA_END_GZ_TOO_LARGE, 1));
@@ -324,7 +341,7 @@ static int gzip_run_batch(struct archive_read_filter *self, struct gzip_private 
 				stop = 1;
 				break;
 			}
-			st->hint_cap = base < 32768 ? 65536 : (base > 0x3FFFFFFFu ? 0x80000000u : base * 2);
+			st->hint_cap = base < 32768 ? 65536 : (base > st->slot_limit / 2 ? st->slot_limit : base * 2);
 			st->hint_skip = i == 0 ? prev_skip : 0;
 			stop = 1;
 			break;

@@ -109,7 +109,17 @@ static int lz4_reader_bid(struct archive_read_filter_bidder *self, struct archiv
 	const unsigned char *p = __archive_read_filter_ahead(filter, 11, &avail);
 	if (p == NULL)
 		return 0;
-	return la_lz4_bid_bytes(p, 11);
+	const int bits = la_lz4_bid_bytes(p, 11);
+	/* Default policy (la_bid_policy.c): a frame WITH a content checksum that does not end inside the look-ahead is
+	 * bound by one XXH32 chain (one DPP row, two thirds of a host core's rate): not bid for. */
+	if (bits > 0 && !la_bid_take_all()) {
+		const size_t la = la_bid_lookahead(1024);
+		size_t got = 0;
+		const unsigned char *w = la_bid_peek(filter, la, &got);
+		if (w != NULL && !la_bid_lz4_parallel(w, got, la))
+			return 0;
+	}
+	return bits;
 }
 
 static int gpu_fail(struct archive_read_filter *self, struct lz4_private *st, const char *what)

@@ -24,6 +24,8 @@ struct zstd_private {
 	/* stage: compressed bytes not decoded yet */
 	uint8_t *stage; size_t stage_len, stage_cap;
 	int upstream_eof;
+	uint64_t skip_left;		/* bytes of a skippable frame still to pass over before anything is staged (zstd.c skips
+					 * such frames in constant memory: so does this filter) */
 	/* one decoded window */
 	la_zstd_frame *frames; uint32_t frames_cap;
 	la_zstd_result *results;
@@ -66,7 +68,17 @@ static int zstd_reader_bid(struct archive_read_filter_bidder *self, struct archi
 	const unsigned char *p = __archive_read_filter_ahead(filter, 4, &avail);
 	if (p == NULL)
 		return 0;
-	return la_zstd_bid_bytes(p, 4);
+	const int bits = la_zstd_bid_bytes(p, 4);
+	/* Default policy (la_bid_policy.c): a frame is one serial chain (one wave); a stream whose first frame does not
+	 * end inside the look-ahead is left to libzstd on a host core. */
+	if (bits > 0 && !la_bid_take_all()) {
+		const size_t la = la_bid_lookahead(1024);
+		size_t got = 0;
+		const unsigned char *w = la_bid_peek(filter, la, &got);
+		if (w != NULL && !la_bid_zstd_parallel(w, got, la))
+			return 0;
+	}
+	return bits;
 }
 
 static int zstd_reader_init(struct archive_read_filter *self)
@@ -132,6 +144,29 @@ static int zstd_fill(struct archive_read_filter *self, struct zstd_private *st, 
 			st->upstream_eof = 1;
 			break;
 		}
+		if (st->skip_left) {
+			/* the rest of a skippable frame: consumed, never copied */
+			const uint64_t k = st->skip_left < (uint64_t)avail ? st->skip_left : (uint64_t)avail;
+			__archive_read_filter_consume(self->upstream, (int64_t)k);
+			st->skip_left -= k;
+			continue;
+		}
+		if (st->stage_len >= 8 && st->stage_len < 8 + (uint64_t)0xFFFFFFFFu) {
+			/* a stage that BEGINS with a skippable frame (0x184D2A5x + 32-bit size, zstd.c:107-131 / RFC 8878 3.1.2):
+			 * drop what is there of it and remember how much is still to come */
+			const uint32_t mg = (uint32_t)st->stage[0] | (uint32_t)st->stage[1] << 8 | (uint32_t)st->stage[2] << 16 | (uint32_t)st->stage[3] << 24;
+			if ((mg & 0xFFFFFFF0u) == 0x184D2A50u) {
+				const uint64_t total = 8ull + ((uint64_t)st->stage[4] | (uint64_t)st->stage[5] << 8 | (uint64_t)st->stage[6] << 16 | (uint64_t)st->stage[7] << 24);
+				if (total <= st->stage_len) {
+					memmove(st->stage, st->stage + total, st->stage_len - (size_t)total);
+					st->stage_len -= (size_t)total;
+				} else {
+					st->skip_left = total - st->stage_len;
+					st->stage_len = 0;
+				}
+				continue;
+			}
+		}
 		size_t n = (size_t)avail;
 		if (n > want - st->stage_len)
 			n = want - st->stage_len;
@@ -173,6 +208,14 @@ static int zstd_next_window(struct archive_read_filter *self, struct zstd_privat
 			}
 		}
 		la_zstd_index_build(st->stage, st->stage_len, st->upstream_eof, st->out_budget, st->frames, st->frames_cap, &ir);
+		if (ir.n_frames == 0 && ir.end_kind == LA_END_NEED_MORE && !ir.window_full && !st->upstream_eof && ir.consumed > 0) {
+			/* nothing but skippable frames in front of an incomplete frame: they are done with -- drop them and gather
+			 * on in the same window (the reference skips such frames in constant memory, zstd.c:196-260; growing the
+			 * window for them ended in "frame too large" once they passed LA_GPU_MAX_BATCH_MIB) */
+			memmove(st->stage, st->stage + ir.consumed, st->stage_len - (size_t)ir.consumed);
+			st->stage_len -= (size_t)ir.consumed;
+			continue;
+		}
 		if (ir.n_frames == 0 && ir.end_kind == LA_END_NEED_MORE && !ir.window_full && !st->upstream_eof) {
 			if (st->stage_len >= st->max_batch_bytes) {
 				/* ONE frame whose compressed bytes alone pass LA_GPU_MAX_BATCH_MIB: the whole frame would have to sit in

@@ -51,13 +51,17 @@
 struct zip_entry {
 	uint64_t lho, data_off, csize, usize;
 	uint64_t slab_off;		/* where its decoded bytes sit in the batch slab */
-	uint32_t crc, name_off;
+	uint32_t crc;
+	uint64_t name_off;	/* offset of the name inside the gathered image (the central directory may lie beyond 4 GiB) */
 	int64_t mtime;
 	uint16_t method, flags, name_len;
 	unsigned mode;
 	uint8_t system;			/* "version made by" high byte: 3 = Unix */
 	uint8_t version;		/* version needed to extract */
 };
+
+/* (offsets into the gathered image are 64-bit: a Zip64 central directory lies beyond 4 GiB) */
+_Static_assert(sizeof(((struct zip_entry *)0)->name_off) == 8, "zip_entry.name_off must hold an offset into an image of up to LA_ZIP_MAX_MIB");
 
 struct zip_private {
 	la_gpu_ctx *gpu;
@@ -206,7 +210,7 @@ static int zip_load(struct archive_read *a, struct zip_private *z)
 		e->lho = le32(h + 42);
 		if (p + 46 + nlen + elen + clen > cd_end)
 			return zip_fail(a, ARCHIVE_FATAL, "Damaged ZIP central directory");
-		e->name_off = (uint32_t)(p + 46);
+		e->name_off = (uint64_t)(p + 46);
 		e->name_len = (uint16_t)nlen;
 		/* Zip64 extended information (0x0001): the 8-byte forms of whichever fields read 0xffffffff, in order */
 		const uint8_t *x = h + 46 + nlen, *xe = x + elen;
@@ -465,7 +469,9 @@ int archive_read_support_format_zip(struct archive *_a)
 		return ARCHIVE_FATAL;
 	}
 	struct archive_format_descriptor d = { z, "zip", zip_bid, zip_read_header, zip_read_data, zip_cleanup, zip_skip };
-	if (__archive_read_register_format(a, d) != ARCHIVE_OK)
+	if (__archive_read_register_format(a, d) != ARCHIVE_OK) {
 		free(z);
+		return ARCHIVE_FATAL;	/* (the core has set the error: no free format slot) */
+	}
 	return ARCHIVE_OK;
 }

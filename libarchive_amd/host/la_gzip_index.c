@@ -108,6 +108,18 @@ static int push(la_gz_index *x)
  * members (they do not say how long they are).  Two compares per 32 bytes where AVX2 is there, memchr otherwise. */
 #if defined(__x86_64__)
 #include <immintrin.h>
+
+/* Largest compressed span of ONE member the tables can express (32-bit fields).  LA_GZ_TEST_SPAN_LIMIT lowers it
+ * so that the refusal path (LA_END_GZ_TOO_LARGE, "gzip member too large ...") can be reached by a test without a
+ * 4 GiB input; it cannot raise it. */
+uint64_t la_gz_span_limit(void)
+{
+	const char *v = getenv("LA_GZ_TEST_SPAN_LIMIT");
+	uint64_t lim = 0xFFFFFFFFull;
+	if (v != NULL && strtoull(v, NULL, 10) > 0 && strtoull(v, NULL, 10) < lim)
+		lim = strtoull(v, NULL, 10);
+	return lim;
+}
 __attribute__((target("avx2")))
 static uint64_t find_magic_avx2(const uint8_t *p, uint64_t len, uint64_t i)
 {
@@ -249,7 +261,7 @@ int la_gz_index_build4(const uint8_t *img, uint64_t len, int at_eof, uint32_t fi
 			}
 		}
 		uint64_t span = next - body;
-		if (span > 0xFFFFFFFFull) {
+		if (span > la_gz_span_limit()) {
 			x->end_kind = LA_END_GZ_TOO_LARGE;	/* > 4 GiB member: beyond the table's u32 fields */
 			break;
 		}

@@ -240,14 +240,30 @@ static int dev_ready(void)
 {
 	if (dev_state == 0) {
 		const uint32_t nj = LA_HASH_GPU_STAGE / LA_HASH_GPU_RANGE;
+		/* the same device as the filters and the ZIP reader (its caller for stored entries) use */
+		const char *dv = getenv("LA_GPU_DEVICE");
+		const int device = dv != NULL ? atoi(dv) : 0;
 		dev_state = -1;
-		if (la_gpu_open(0, &dev_ctx) == LA_OK &&
+		if (la_gpu_open(device, &dev_ctx) == LA_OK &&
 		    la_gpu_malloc(dev_ctx, &dev_buf, LA_HASH_GPU_STAGE) == LA_OK &&
 		    la_gpu_malloc(dev_ctx, &dev_jobs, nj * sizeof(la_hash_job)) == LA_OK &&
 		    la_gpu_malloc(dev_ctx, &dev_out, nj * sizeof(uint32_t)) == LA_OK &&
 		    (host_jobs = (la_hash_job *)malloc(nj * sizeof(la_hash_job))) != NULL &&
-		    (host_out = (uint32_t *)malloc(nj * sizeof(uint32_t))) != NULL)
+		    (host_out = (uint32_t *)malloc(nj * sizeof(uint32_t))) != NULL) {
 			dev_state = 1;
+		} else if (dev_ctx != NULL) {
+			/* a later step failed: nothing of the half-built state stays behind */
+			if (dev_buf) (void)la_gpu_free(dev_ctx, dev_buf);
+			if (dev_jobs) (void)la_gpu_free(dev_ctx, dev_jobs);
+			if (dev_out) (void)la_gpu_free(dev_ctx, dev_out);
+			free(host_jobs);
+			free(host_out);
+			la_gpu_close(dev_ctx);
+			dev_ctx = NULL;
+			dev_buf = dev_jobs = dev_out = NULL;
+			host_jobs = NULL;
+			host_out = NULL;
+		}
 	}
 	return dev_state == 1;
 }

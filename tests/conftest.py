@@ -9,6 +9,11 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
+# The parity tests decode EVERY stream shape, lone members and single frames included, so they run with the bid policy
+# switched off; the policy itself (the product's default, LA_GPU_BID=auto) is what tests/test_gpu_bid_policy.py checks.
+os.environ.setdefault("LA_GPU_BID", "all")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     # CPU-side native pieces (oracle, host C, generators) are cheap to (re)build with gcc.

@@ -163,3 +163,21 @@ def test_zstd_one_frame_larger_than_the_gather_limit(gpu_ctx, monkeypatch):
     monkeypatch.setenv("LA_GPU_MAX_BATCH_MIB", "1")
     res = la_api.cat(img, read_size=65536)
     assert res.rc == la_api.ARCHIVE_FATAL and res.error.startswith("zstd frame too large for the GPU data plane (more than"), res.error
+
+
+def test_zstd_frame_of_compressed_blocks_beyond_the_window_budget(gpu_ctx, monkeypatch):
+    """The same refusal for a frame made of COMPRESSED blocks (libzstd level 3 over 6 MiB of text-like data, window
+    descriptor in the header, no content size): with the decoded-bytes budget of a window at 1 MiB the frame's 48
+    blocks ask for more than that and the frame is refused by name; with the default budget it decodes bit for bit."""
+    z = _z()
+    rnd = random.Random(99)
+    words = [bytes(rnd.choice(b"abcdefghijklmnopqrstuvwxyz ") for _ in range(rnd.randint(2, 9))) for _ in range(500)]
+    plain = bytearray()
+    while len(plain) < 6 << 20:
+        plain += rnd.choice(words)
+    plain = bytes(plain[:6 << 20])
+    img = Z.zstd_compress(z, plain, 3)
+    assert la_api.as_reference_tuple(la_api.cat(img, read_size=65536)) == (plain, 0, "")
+    monkeypatch.setenv("LA_GPU_OUT_BUDGET_MIB", "1")
+    res = la_api.cat(img, read_size=65536)
+    assert res.rc == la_api.ARCHIVE_FATAL and res.error.startswith("zstd frame too large for the GPU data plane"), res.error

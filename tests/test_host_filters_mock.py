@@ -28,6 +28,11 @@ def gpu_ctx():
 
 
 # the test functions themselves (their module-level `gpu` mark stays behind in that module)
+from test_gpu_bid_policy import (  # noqa: E402,F401
+    test_gzip_large_single_member_is_declined_many_members_are_taken,
+    test_lz4_single_frame_with_content_checksum_is_declined,
+    test_zstd_one_large_frame_is_declined_small_frames_are_taken,
+)
 from test_gpu_filters import (  # noqa: E402,F401
     test_reference_fixtures_through_the_api,
     test_gzip_entry_metadata_from_fixture,
@@ -184,3 +189,60 @@ def test_dependent_frame_really_used_the_carried_history(gpu_ctx, monkeypatch):
     before = lib.la_gpu_mock_hist_blocks()
     test_lz4_dependent_frame_across_windows(gpu_ctx, monkeypatch)
     assert lib.la_gpu_mock_hist_blocks() - before >= 3 * 4 * 5
+
+
+# ---- CPU-only additions (host logic that needs no device): refusal paths with lowered limits ----
+
+def _gz_member(data, level=1, isize=None):
+    import zlib, struct
+    co = zlib.compressobj(level, zlib.DEFLATED, -15)
+    body = co.compress(data) + co.flush()
+    return (b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x00\x03" + body +
+            struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, (len(data) if isize is None else isize) & 0xFFFFFFFF))
+
+
+def test_gzip_member_beyond_the_span_limit_is_refused_by_name(gpu_ctx, monkeypatch):
+    """The 4 GiB guard of the member table (la_gzip_index.c: 32-bit span) with the limit lowered to 200 000 bytes:
+    members in front of the oversized one are delivered, then the explicit message -- never a wrapped span."""
+    import random
+    rnd = random.Random(11)
+    ok_plain = rnd.randbytes(50_000)
+    big_plain = rnd.randbytes(400_000)           # incompressible: the member's span is > 200 000 bytes
+    img = _gz_member(ok_plain) + _gz_member(big_plain)
+    monkeypatch.setenv("LA_GZ_TEST_SPAN_LIMIT", "200000")
+    r = la_api.cat(img)
+    assert r.rc == la_api.ARCHIVE_FATAL and r.error == "gzip member too large for the GPU data plane (4 GiB limit)"
+    assert ok_plain.startswith(r.data) and len(r.data) <= len(ok_plain)      # whole 64 KiB blocks in front of the error
+    monkeypatch.delenv("LA_GZ_TEST_SPAN_LIMIT")
+    r = la_api.cat(img)
+    assert r.rc == la_api.ARCHIVE_EOF and r.data == ok_plain + big_plain
+
+
+def test_gzip_slot_that_cannot_grow_any_further_is_refused_by_name(gpu_ctx, monkeypatch):
+    """The 2 GiB guard of an output slot (la_filter_gzip.c) with the limit lowered to 256 KiB: a member whose ISIZE
+    field claims 10 bytes but holds 1 MiB makes the filter retry with doubled slots until the limit, then stop with
+    the explicit message instead of retrying for ever or delivering a wrapped slot."""
+    plain = bytes(range(256)) * 4096             # 1 MiB, compresses well: the span is small, the output is not
+    img = _gz_member(plain, level=6, isize=10)
+    monkeypatch.setenv("LA_GZ_TEST_SLOT_LIMIT", "262144")
+    r = la_api.cat(img)
+    assert r.rc == la_api.ARCHIVE_FATAL and r.error == "gzip member too large for the GPU data plane (4 GiB limit)"
+    monkeypatch.delenv("LA_GZ_TEST_SLOT_LIMIT")
+    r = la_api.cat(img)
+    assert r.rc == la_api.ARCHIVE_EOF and r.data == plain
+
+
+def test_zstd_skippable_frames_larger_than_the_window_are_passed_over(gpu_ctx, monkeypatch):
+    """Skippable frames that alone fill (and pass) a gather window are dropped and the window is reused -- the stream
+    is not refused as "frame too large" (zstd.c:196-260 skips them in constant memory)."""
+    import zstd_support as Z
+    z = Z.libzstd()
+    if z is None:
+        pytest.skip("no libzstd.so.1 in this image")
+    a, b = b"first frame " * 1000, b"second frame " * 1000
+    skip = Z.skippable(b"\0" * (3 << 20), 5)     # 3 MiB of skippable payload, window and stage limit are 1 MiB
+    img = Z.zstd_compress(z, a, 3) + skip + skip + Z.zstd_compress(z, b, 3) + skip
+    monkeypatch.setenv("LA_GPU_BATCH_MIB", "1")
+    monkeypatch.setenv("LA_GPU_MAX_BATCH_MIB", "1")
+    r = la_api.cat(img, read_size=65536)
+    assert r.rc == la_api.ARCHIVE_EOF and r.error is None and r.data == a + b

@@ -180,7 +180,7 @@ def test_filters_read_core_and_tar_walker_under_asan_ubsan(tmp_path):
     mock = os.path.join(ROOT, "tests", "mock_gpu")
     orc = os.path.join(ROOT, "oracle")
     srcs = [os.path.join(host, f) for f in ("la_lz4_index.c", "la_gzip_index.c", "la_read_core.c", "la_format_tar.c",
-                                            "la_format_zip.c", "la_hash_dropin.c", "la_write_filters.c", "la_filter_lz4.c", "la_filter_gzip.c", "la_filter_zstd.c", "la_zstd_index.c")]
+                                            "la_format_zip.c", "la_hash_dropin.c", "la_write_filters.c", "la_filter_lz4.c", "la_filter_gzip.c", "la_filter_zstd.c", "la_bid_policy.c", "la_zstd_index.c")]
     srcs += [os.path.join(mock, "la_gpu_mock.c")] + [os.path.join(orc, f) for f in ("orc_hash.c", "orc_lz4.c", "orc_inflate.c", "orc_zstd.c")]
     subprocess.check_call(["gcc", "-O1", "-g", "-fPIC", "-std=gnu11", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
                            "-I" + os.path.join(ROOT, "include"), "-shared", "-o", os.path.join(mock, "libla_host_mock_asan.so")] + srcs)

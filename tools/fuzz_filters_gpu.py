@@ -4,6 +4,7 @@ so that every stream crosses several windows (two in flight for lz4), frames / m
 crossing the borders, mutations, truncations, junk; bytes, return code and error string against the oracle.
 usage: python tools/fuzz_filters_gpu.py [seconds per codec]"""
 import os, random, sys, time
+os.environ.setdefault("LA_GPU_BID", "all")   # every stream shape is decoded here, lone units included (the bid policy has its own test)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 os.environ["LA_GPU_BATCH_MIB"] = "1"

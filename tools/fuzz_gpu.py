@@ -3,6 +3,7 @@
 truncated lz4 streams and deflate members, every kernel variant against the oracle.
 usage: python tools/fuzz_gpu.py [seconds per codec]"""
 import os, random, sys, time, zlib
+os.environ.setdefault("LA_GPU_BID", "all")   # every stream shape is decoded here, lone units included (the bid policy has its own test)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch

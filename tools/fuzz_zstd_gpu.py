@@ -4,6 +4,7 @@ device kernels, against the oracle (oracle/orc_zstd.c, checker only): clean, bit
 streams made with the image's libzstd.  Outside the pytest suite; the result is committed under profiles/.
 usage (GPU box): python tools/fuzz_zstd_gpu.py [seconds=60]"""
 import os, random, sys, time
+os.environ.setdefault("LA_GPU_BID", "all")   # every stream shape is decoded here, lone units included (the bid policy has its own test)
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
 import la_api

@@ -2,6 +2,7 @@
 """Diagnostic: ONE lz4 frame of many 64 KiB blocks through la_cat (bounded windows), with the
 content checksum that serialises its hashing.  usage: python tools/measure_single_frame.py [MiB]"""
 import os, subprocess, sys, time
+os.environ.setdefault("LA_GPU_BID", "all")   # these measure the lone-unit shapes the default bid policy declines
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import streams as S

@@ -3,6 +3,7 @@
 bit chain, so one lane of one wave decodes it).  Reported so that the limit is on record, not as a result to be proud of.
 usage (GPU box): python tools/measure_single_member_gz.py [MiB ...]"""
 import os, subprocess, sys, time, zlib
+os.environ.setdefault("LA_GPU_BID", "all")   # these measure the lone-unit shapes the default bid policy declines
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np

@@ -4,6 +4,7 @@ the same stream through la_cat (file -> filter -> archive_read_data_block, PCIe 
 stream (this design's worst case), and the image's libzstd on one host core beside them.
 usage: python tools/measure_zstd.py [frames=16384] [frame_kib=64] [level=3]"""
 import ctypes, os, subprocess, sys, time
+os.environ.setdefault("LA_GPU_BID", "all")   # the one-frame measurement is a shape the default bid policy declines
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
