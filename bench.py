@@ -235,6 +235,28 @@ def _gz_make_member(args):
 
 
 
+def measured_copy_peak(ctx, torch, mib=2048, reps=5):
+    """Device copy microbenchmark beside the 8 TB/s vendor figure (report both): a 16-byte-per-lane
+    device-to-device copy of `mib` MiB (torch's copy kernel on the context's stream, far larger than the 256 MiB
+    Infinity Cache), HIP events on that stream; GB/s counts bytes read + bytes written.  Outside every timed region."""
+    n = mib << 20
+    a = torch.empty(n, dtype=torch.uint8, device="cuda")
+    b = torch.empty(n, dtype=torch.uint8, device="cuda")
+    a.random_(0, 255)
+    b.copy_(a)
+    ctx.sync()
+    best = None
+    for _ in range(reps):
+        ctx.timer_start()
+        b.copy_(a)
+        ms = ctx.timer_stop()
+        best = ms if best is None or ms < best else best
+    del a, b
+    torch.cuda.empty_cache()
+    return {"GBps": round(2 * n / (best * 1e-3) / 1e9, 1), "bytes_copied": n, "ms": round(best, 4),
+            "how": "torch device copy (16 B per lane), read + written bytes / best of %d" % reps}
+
+
 def zstd_object(ctx, torch):
     """SURVEY 8f-3 in the same driver-run command: 16 384 zstd frames of 64 KiB (libzstd level 3 output of synthetic
     text-like data, 64 distinct frames tiled) through la_gpu_zstd_decode, inputs resident in HBM, every frame's status
@@ -564,14 +586,15 @@ def main():
         # passes, tools/exp_traffic.sh, committed under profiles/), per slice launch like `achieved`.
         # The file names the kernel source it was measured on: a stale file is refused, not quoted.
         traffic, traffic_note = None, None
-        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
         if os.path.exists(tpath) and abs(args.gib - 16.0) < 1e-6 and not args.general_only and not args.extra_options:
             rec = json.load(open(tpath))
             if rec.get("library_sha16") == kernel_source_id():
                 traffic = rec["lz4_expand_fast_kernel"]["hbm_bytes_per_launch"]
             else:
-                traffic_note = "profiles/r02_traffic.json was measured on another build of libla_gpu.so (%s, now %s): not quoted" % (
+                traffic_note = "profiles/r03_traffic.json was measured on another build of libla_gpu.so (%s, now %s): not quoted" % (
                     rec.get("library_sha16"), kernel_source_id())
+        copy_peak = measured_copy_peak(ctx, torch) if world == 1 else None
         nl = 4 if (plan.n_blocks >= 32768 and not args.general_only) else 1   # slice launches of the expand kernel per step
         # per-launch algorithmic bytes / per-launch duration (the slices are equal, so this is the ratio of the sums)
         achieved = (C_bytes + U_bytes) / (exp_ms * 1e-3) / 1e9
@@ -619,6 +642,9 @@ def main():
                 "traffic_note": traffic_note,
                 "launch_ms": round(exp_ms / nl, 4),
                 "whole_step_frac": round((C_bytes + U_bytes) / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                # measured on this box beside the vendor peak (`peak`, which `frac` is quoted against)
+                "peak_measured_copy": copy_peak,
+                "frac_of_measured_copy": round(achieved / copy_peak["GBps"], 4) if copy_peak else None,
             },
             "cpu_baseline": cpu,
             "api_level": api,

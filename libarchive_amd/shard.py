@@ -88,9 +88,12 @@ def exchange_summaries(dist, device, elapsed_s: float, decoded_bytes: int, compr
 
 
 def gather_ranges_into(dist, device, local_bytes, root: int = 0):
-    """The same gather without the final concatenation: the root receives every rank's range into
-    equal slots of ONE preallocated buffer (what a 100+ GiB gather can afford).  Returns
-    (buffer, slot_bytes, sizes) on the root, (None, slot_bytes, sizes) elsewhere."""
+    """The same gather without the final concatenation and without padding: the root posts one receive per peer
+    straight into that peer's slot of ONE preallocated buffer (slots of max-size bytes, what a 100+ GiB gather can
+    afford), every other rank sends exactly its own bytes -- no rank pads or copies its range (round 2 padded every
+    range to the largest one and went through dist.gather).  Point-to-point on purpose: xGMI is point-to-point
+    (seven links per GPU), the root's seven receives run on seven links.  Returns (buffer, slot_bytes, sizes) on the
+    root, (None, slot_bytes, sizes) elsewhere."""
     import torch
     world = dist.get_world_size()
     rank = dist.get_rank()
@@ -99,15 +102,16 @@ def gather_ranges_into(dist, device, local_bytes, root: int = 0):
     dist.all_gather(sizes, n)
     sizes = [int(s[0]) for s in sizes]
     mx = max(sizes) if sizes else 0
-    if local_bytes.numel() != mx:
-        pad = torch.zeros(mx, dtype=torch.uint8, device=device)
-        pad[:local_bytes.numel()] = local_bytes
-    else:
-        pad = local_bytes
-    buf = torch.empty(world * mx, dtype=torch.uint8, device=device) if rank == root else None
-    bufs = [buf[r * mx:(r + 1) * mx] for r in range(world)] if rank == root else None
-    dist.gather(pad, bufs, dst=root)
-    return buf, mx, sizes
+    if rank == root:
+        buf = torch.empty(world * mx, dtype=torch.uint8, device=device)
+        reqs = [dist.irecv(buf[r * mx:r * mx + sizes[r]], src=r) for r in range(world) if r != root and sizes[r]]
+        buf[root * mx:root * mx + sizes[root]] = local_bytes      # the root's own range: one device copy
+        for q in reqs:
+            q.wait()
+        return buf, mx, sizes
+    if local_bytes.numel():
+        dist.send(local_bytes.contiguous(), dst=root)
+    return None, mx, sizes
 
 
 def gather_ranges(dist, device, local_bytes, root: int = 0):

@@ -91,3 +91,15 @@ def test_two_ranks_shard_and_exchange():
     full_img, full_plain = S.synth_lz4_stream(11, 0, FRAMES, BPF, BS, nthreads=1)
     assert ok and dt == 1.5 and U == full_plain.size and C == full_img.size
     assert whole == full_plain.tobytes()
+
+
+def test_bench_refuses_a_gpus_world_size_mismatch():
+    """`bench.py --gpus 2` inside a launcher that started ONE rank (WORLD_SIZE=1) must stop with the mismatch message
+    before touching a GPU -- a line with n_gpus 2 timed on one rank would be a wrong scaling point."""
+    import subprocess, sys
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    assert "--gpus 2 but WORLD_SIZE=1" in (p.stderr + p.stdout)
