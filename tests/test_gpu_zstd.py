@@ -165,19 +165,21 @@ def test_zstd_one_frame_larger_than_the_gather_limit(gpu_ctx, monkeypatch):
     assert res.rc == la_api.ARCHIVE_FATAL and res.error.startswith("zstd frame too large for the GPU data plane (more than"), res.error
 
 
-def test_zstd_frame_of_compressed_blocks_beyond_the_window_budget(gpu_ctx, monkeypatch):
-    """The same refusal for a frame made of COMPRESSED blocks (libzstd level 3 over 6 MiB of text-like data, window
-    descriptor in the header, no content size): with the decoded-bytes budget of a window at 1 MiB the frame's 48
-    blocks ask for more than that and the frame is refused by name; with the default budget it decodes bit for bit."""
-    z = _z()
-    rnd = random.Random(99)
-    words = [bytes(rnd.choice(b"abcdefghijklmnopqrstuvwxyz ") for _ in range(rnd.randint(2, 9))) for _ in range(500)]
-    plain = bytearray()
-    while len(plain) < 6 << 20:
-        plain += rnd.choice(words)
-    plain = bytes(plain[:6 << 20])
-    img = Z.zstd_compress(z, plain, 3)
-    assert la_api.as_reference_tuple(la_api.cat(img, read_size=65536)) == (plain, 0, "")
-    monkeypatch.setenv("LA_GPU_OUT_BUDGET_MIB", "1")
-    res = la_api.cat(img, read_size=65536)
-    assert res.rc == la_api.ARCHIVE_FATAL and res.error.startswith("zstd frame too large for the GPU data plane"), res.error
+def test_zstd_frame_of_compressed_blocks_beyond_the_window_budget(gpu_ctx):
+    """The same refusal for a frame made of COMPRESSED blocks (not RLE): 40 000 blocks of {one raw literal, no
+    sequences} -- three bytes each, one decoded byte each, but a compressed block may decode to 128 KiB and the header
+    carries no content size, so the walker must reserve 5 GiB for the frame: refused by name.  A hundred of the same
+    blocks decode bit for bit (the block really is a valid compressed block)."""
+    hdr = (0xFD2FB528).to_bytes(4, "little") + bytes([0x00, 0x70])       # no content size, window descriptor
+
+    def frame(nb):
+        body = bytearray()
+        for i in range(nb):
+            bh = (1 if i == nb - 1 else 0) | (2 << 1) | (3 << 3)             # last?, Compressed_Block, Block_Size 3
+            body += bh.to_bytes(3, "little") + bytes([0x08, 0x78, 0x00])     # raw literals of size 1 ("x"), 0 sequences
+        return hdr + bytes(body)
+
+    assert la_api.as_reference_tuple(la_api.cat(frame(100))) == (b"x" * 100, 0, "")
+    res = la_api.cat(frame(40000))
+    assert res.rc == la_api.ARCHIVE_FATAL
+    assert res.error.startswith("zstd frame too large for the GPU data plane (its blocks may decode to"), res.error

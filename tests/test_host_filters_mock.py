@@ -77,6 +77,7 @@ from test_gpu_zstd import (  # noqa: E402,F401
     test_zstd_garbage_behind_a_frame,
     test_zstd_frame_whose_blocks_claim_more_than_the_window_budget,
     test_zstd_one_frame_larger_than_the_gather_limit,
+    test_zstd_frame_of_compressed_blocks_beyond_the_window_budget,
 )
 
 from test_gpu_zip import (  # noqa: E402,F401
