@@ -1,43 +1,61 @@
 /*
- * la_lz4_inorder.hip -- in-order LDS-window LZ4 expand kernel (gfx950): the hot kernel of the
- * lz4 filter path for independent blocks of at most 64 KiB
- * (libarchive/archive_read_support_filter_lz4.c:557-561, the LZ4_decompress_safe call of BD=4
- * frames), and the second phase of the two-phase inflate (archive_read_support_filter_gzip.c:479).
+ * la_lz4_inorder.hip -- in-order LDS-window LZ4 expand kernel (gfx950), round 3: a SECOND implementation of the
+ * expand step of the lz4 filter path for independent blocks of at most 64 KiB
+ * (libarchive/archive_read_support_filter_lz4.c:557-561, the LZ4_decompress_safe call of BD=4 frames) and of the
+ * second phase of the two-phase inflate (archive_read_support_filter_gzip.c:479).  Selected with
+ * LA_LZ4_OPT_EXPAND_INORDER / LA_GZ_OPT_EXPAND_INORDER; every lz4 / deflate GPU test runs it beside the default
+ * kernel (la_lz4_fast.hip) and requires identical bytes.  It is NOT the default: on the C2 stream it reaches
+ * 0.10 - 0.12 of the 8 TB/s roofline against 0.14 for the polling kernel (profiles/r03_inorder_experiments.md has
+ * every measurement quoted below).
  *
- * Round 3.  The round-1/2 kernel (la_lz4_fast.hip, kept as the cross-check) gave every sequence to a
- * thread and let matches POLL per-sequence done bits: 31 poll iterations per wave and block, each one
- * running the whole (divergent) copy code for a handful of ready lanes -- 47 k instructions per block, half
- * of the wave cycles waiting.  This kernel has no flags per sequence, no search and no polling in the
- * match phase at all.  It rests on one hardware fact: the LDS serves the DS instructions of ONE wave in
- * program order.  So a single wave that takes the block's sequences IN STREAM ORDER, 64 at a time (one
- * per lane), sees every byte that an earlier group produced without any synchronisation; only a match
- * whose source reaches into its OWN group has to wait, and those (about one lane in twenty on the C2
- * stream) are finished in a few more passes over the same registers.
+ * Idea.  The polling kernel gives every sequence to a thread and lets matches POLL per-sequence done bits: 31 poll
+ * iterations per wave and block, each running the divergent copy code for a handful of ready lanes.  This kernel has
+ * no flags per sequence and no polling in the match phase.  It rests on one hardware fact: the LDS executes the DS
+ * instructions of ONE wave in program order.  A single wave that takes the block's sequences IN STREAM ORDER, 64 at
+ * a time (one per lane), sees every byte an earlier group produced without any synchronisation; only a match whose
+ * source reaches into a match of its OWN group has to wait, and those (about one lane in eighteen on C2) follow in
+ * one or two more passes over the same registers.
  *
- * One workgroup = three waves with fixed roles that share a 64 KiB LDS window (two workgroups per CU),
- * persistent over IO_BPW consecutive blocks:
+ * One workgroup = 64 KiB LDS window + fixed roles (two workgroups per CU), persistent over IO_BPW consecutive blocks:
+ *   waves 1..IO_LWAVES, L (literals + planning)  run AHEAD of the matcher; the groups of 64 sequences are shared
+ *       out by their running number.  Per group: table entries (coalesced 8 bytes per lane) two groups ahead,
+ *       each lane's literal run straight from the compressed payload (two unaligned 16-byte global loads, one group
+ *       ahead, addresses clamped into the image instead of predicated so that no load is waited for behind its
+ *       issue), exact-length LDS stores of the literals, then for every match: where, how long, from where, and
+ *       WHICH lanes of the same group its source overlaps (two binary searches over the lanes, ds_bpermute) --
+ *       written as one tagged 16-byte record per sequence into a ring (the tag is the group's running number: all
+ *       64 records appear with one ds_write_b128, after the group's literals).
+ *   wave 0, M (matches)  per group: the records (requested with the previous group's loads; the tag says whether
+ *       they are there), eleven length-class masks, then pass 1 = every match without an in-group dependency as ONE
+ *       straight line of predicated DS instructions (io_copy_fast, la_dev.h), then rounds: a lane is ready when none
+ *       of the lanes it waits for is unfinished.  Matches of more than 64 bytes or overlapping their source take the
+ *       generic per-lane path (period doubling).  After each group M publishes the window position up to which
+ *       everything is final, and the group count (the ring slot is free).
+ *   last wave, F (flush)  trails M: copies the final part of the window to the decoded slab in 4 KiB steps
+ *       (16-byte aligned LDS reads, coalesced 16-byte stores; window and slab addresses are congruent modulo 16)
+ *       and hands the window back to L when the block is out.
+ * No __syncthreads() after the start; every spin is bounded and watches a common abort word; a wave that gives up
+ * marks the block and lets the workgroup run out (no early return: see IO_FAIL).
  *
- *   wave 1, L (literals)   runs AHEAD of the matcher: per group of 64 sequences it loads the table
- *       entries (coalesced 8 bytes per lane, two groups in flight) and each lane's literal run straight
- *       from the compressed payload (two unaligned 16-byte global loads, requested one group ahead),
- *       stores it into the window with exact-length LDS stores, and bumps `lit_total`.
- *   wave 0, M (matches)    per group: waits (normally not at all) until L has passed the group, then
- *       pass 1 copies every match whose source ends before the group's first match -- all loads of a lane
- *       before its stores, 16 bytes per LDS access -- and the few remaining lanes follow in rounds: a
- *       lane is ready once its source ends before the match of the lowest unfinished lane (everything
- *       below that is final).  Overlapping matches (offset < length) double their period in place.
- *       After each group M publishes the window position up to which everything is final.
- *   wave 2, F (flush)      trails M: copies the final part of the window to the decoded slab in
- *       1 KiB steps (16-byte aligned LDS reads, coalesced 16-byte stores; window and slab addresses are
- *       congruent modulo 16) and hands the window back to L when the block is out.
- *
- * While M works through block j, L has already fetched the descriptor, the first table groups and the
- * first literal bytes of block j+1 and waits only for F's hand-back: HBM latency is off the critical
- * path, which is M's instruction stream.  No __syncthreads() after the start, every spin is bounded and
- * watches a common abort word, so a table that does not add up fails the block instead of hanging.
- *
- * HBM traffic per block: payload once (only literal bytes are touched, every cache line once or twice
- * from L1/L2), the sequence table twice (L and M, the second time from L2), decoded bytes once out.
+ * What was measured (MI355X, C2 blocks: 32.3 groups of 64 sequences per block, 2.2 passes per group):
+ *   - M needs about 2 800 - 3 000 cycles per group: records + masks + publish about 400, pass 1 about 600 - 850,
+ *     the 1.2 later rounds about 1 000 each.  Two blocks per CU: 0.10 - 0.12 of the roofline.
+ *   - The matcher is ONE wave, and a lone wave is bound by the latency of its own instruction stream: about eight
+ *     cycles per dependent instruction, a DS instruction every 15 - 30 cycles WHATEVER the number of lanes it enables
+ *     (profiles/r02_ubench_lds.txt "1 wave"), an LDS round trip of 63 cycles.  A pass of sixteen predicated DS
+ *     instructions therefore costs the same for three lanes as for sixty.  Pass 1 (dense) is efficient, the later
+ *     rounds (three lanes each) are not, and they are on the critical path of every group.
+ *   - What did not help: skipping empty classes with branches (a taken branch costs what an empty DS instruction
+ *     costs), 2 / 6 / 14 literal waves (M's time per group 2 900 / 3 000 / 3 700: more resident waves slow every wave),
+ *     no priority for M, the literal stores or the flush switched off (no change: M is the bottleneck), copying the
+ *     dependent matches one by one with the whole wave instead of rounds (400 cycles per match, 5.25 per group).
+ *   - What would: the later rounds on a second matcher wave beside pass 1 of the next group (needs the dependency
+ *     of every match on the PREVIOUS group's late matches from L as well), or several matcher waves per block with a
+ *     completed-prefix counter; both estimated at 1 400 - 1 800 cycles per group (0.2 - 0.25), not built.
+ * hipcc 7.2 notes: a workgroup of six waves made the compiler pad the register allocation to 129 ("3 waves per SIMD"
+ * derived from the LDS size) and only ONE workgroup fitted a CU -- the workgroup is launched with eight waves, two
+ * leave at once; an early `return` inside the literal waves' group loop was miscompiled (loop-carried prefetch
+ * registers restored from the wrong set after the ring wait; found by the reference's test_compat_lz4_B4 fixture).
  */
 #include "la_dev.h"
 
@@ -47,14 +65,14 @@
 #ifndef IO_LWAVES
 #define IO_LWAVES 6u		/* literal waves per workgroup */
 #endif
-/* M + IO_LWAVES L waves + F = sixteen waves, two workgroups per CU = the CU's 32 wave slots (64 VGPRs each).
- * (A workgroup of SIX waves does not work: the compiler derives "3 waves per SIMD" from the LDS size, pads the
- * register allocation to 129 so that no fourth wave fits, and then the second workgroup's 2+2+1+1 waves do not fit
- * beside the first's -- measured: one workgroup per CU.) */
-#define IO_THREADS (64u * (IO_LWAVES + 2u))
+/* M + L waves + F work; the workgroup is launched with eight waves all the same (the rest leave at once): with two
+ * workgroups of SIX waves per CU the compiler derives "3 waves per SIMD" from the LDS size and pads the register
+ * allocation to 129 so that no fourth wave fits -- and then the second workgroup's 2+2+1+1 waves do not fit beside
+ * the first's (measured: one workgroup per CU).  Eight waves per workgroup make it 4 per SIMD, 2 per SIMD and group. */
+#define IO_THREADS 512u
 #define IO_SPIN_LIMIT (1u << 22)
 #ifndef IO_RING
-#define IO_RING 4u		/* groups of 64 sequences L may be ahead of M (records and literal stores) */
+#define IO_RING 8u		/* groups of 64 sequence records L may be ahead of M */
 #endif
 
 struct io_ctl {
@@ -214,59 +232,6 @@ __device__ __forceinline__ void io_copy_match(uint8_t *mp, uint32_t off, uint32_
 	} while (done < mlen);
 }
 
-/* The few matches of a group that the straight-line pass does not take -- a source that reaches into a match of the
- * same group, more than 64 bytes, a source that overlaps the destination -- are copied one after the other by the
- * WHOLE wave (everything about them is wave-uniform: v_readlane): a lone wave issues a DS instruction every 15 to
- * 30 cycles whatever the number of lanes it enables, so a pass of sixteen predicated DS instructions for three
- * lanes costs as much as for sixty; one read and one write for one match cost a tenth of that.  Taken in stream
- * order they need no readiness test at all: the LDS executes this wave's instructions in order. */
-__device__ __forceinline__ void io_coop_copy(uint8_t *d, const uint8_t *s, uint32_t n, uint32_t lane)
-{
-	/* n bytes, ranges do not overlap; d, s, n wave-uniform */
-	if (n <= 64) {
-		if (lane < n) {
-			const uint8_t b = s[lane];
-			asm volatile("" ::: "memory");
-			d[lane] = b;
-		}
-		return;
-	}
-	uint32_t base = 0;
-	for (; base + 1024 <= n; base += 1024) {
-		const uint4 v = lds_ld16(s + base + 16 * lane);
-		asm volatile("" ::: "memory");
-		lds_st16(d + base + 16 * lane, v);
-	}
-	const uint32_t rem = n - base, nfull = rem >> 4, t0 = base + (nfull << 4), tail = rem & 15u;
-	uint4 v = make_uint4(0, 0, 0, 0);
-	uint8_t b = 0;
-	if (lane < nfull)
-		v = lds_ld16(s + base + 16 * lane);
-	if (lane < tail)
-		b = s[t0 + lane];
-	asm volatile("" ::: "memory");
-	if (lane < nfull)
-		lds_st16(d + base + 16 * lane, v);
-	if (lane < tail)
-		d[t0 + lane] = b;
-}
-
-/* one match, all arguments wave-uniform.  A match that overlaps its source (off < mlen) is a periodic run: the
- * valid stretch behind the source doubles with every step (io_copy_match has the same scheme per lane). */
-__device__ __forceinline__ void io_coop_match(uint8_t *mp, uint32_t off, uint32_t mlen, uint32_t lane)
-{
-	const uint8_t *fp = mp - off;
-	uint32_t done = 0;
-	do {
-		uint32_t nn = off + done;
-		if (nn > mlen - done)
-			nn = mlen - done;
-		io_coop_copy(mp + done, fp, nn, lane);
-		asm volatile("" ::: "memory");
-		done += nn;
-	} while (done < mlen);
-}
-
 /* v >> (8 * bytes) over 128 bits, bytes >= 16 gives zeros (only the last 16 bytes of an image need it) */
 __device__ __forceinline__ uint4 io_shr128(uint4 v, uint32_t bytes)
 {
@@ -310,7 +275,7 @@ __device__ __forceinline__ void io_lit_store(uint8_t *d, const uint4 p0, const u
 	}
 }
 
-__global__ __launch_bounds__(IO_THREADS, 8) void lz4_expand_inorder_kernel(
+__global__ __launch_bounds__(IO_THREADS, 4) void lz4_expand_inorder_kernel(
     const uint8_t *__restrict__ src, uint64_t src_bytes, const la_lz4_block *__restrict__ blocks,
     uint32_t n, uint8_t *__restrict__ dst, uint64_t dst_cap, const uint64_t *__restrict__ dst_off,
     const uint32_t *__restrict__ out_len, uint32_t *status_out,
@@ -321,7 +286,8 @@ __global__ __launch_bounds__(IO_THREADS, 8) void lz4_expand_inorder_kernel(
 	/* 16 bytes of headroom + up to 15 of alignment shift + the window + slack for over-reads */
 	__shared__ __attribute__((aligned(16))) uint8_t win[16 + 16 + 65536 + 96];
 	/* what L has worked out for M, one 16-byte record per sequence, IO_RING groups deep:
-	 *   x = match destination (17 bits) | dep << 29 (the source reaches into the matches of the same group);
+	 *   x = match destination (17 bits) | first << 17 | last << 23 | dep << 29: the lanes first..last of the group
+	 *       are the ones whose matches the source of this match overlaps (dep = 0: none);
 	 *   y = match length, z = match offset, w = running number of the group + 1 -- the tag that tells M the
 	 *       record is there: a group's records are written by ONE ds_write_b128, after its literals. */
 	__shared__ __attribute__((aligned(16))) uint4 ring[IO_RING][64];
@@ -360,9 +326,7 @@ __global__ __launch_bounds__(IO_THREADS, 8) void lz4_expand_inorder_kernel(
 
 	if (wave == 0) {
 		/* ================= M: matches, in stream order ================= */
-#ifndef IO_NO_SETPRIO
 		__builtin_amdgcn_s_setprio(3);
-#endif
 #ifdef LA_DIAG
 		io_acc[12] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -399,13 +363,21 @@ __global__ __launch_bounds__(IO_THREADS, 8) void lz4_expand_inorder_kernel(
 				if (dead)
 					x = make_uint4(0, 0, 0, 0);	/* nothing to copy */
 				IO_STAMP_ADD(1, IO_NOW() - t_w0);
-				if (g == 0)
-					IO_STAMP_ADD(14, IO_NOW() - t_w0);
 				asm volatile("" ::: "memory");
 				const uint32_t mdst = x.x & 0x1FFFFu, mlen = x.y, off = x.z;
-				const bool dep = (x.x >> 29) & 1u;	/* the source reaches into the matches of this group */
+				const uint32_t d_lo = (x.x >> 17) & 63u, d_hi = (x.x >> 23) & 63u;
+				const bool dep = (x.x >> 29) & 1u;
+				/* the lanes this one has to wait for, as a mask */
+#ifdef IO_DBG_NODEP	/* every lower lane counts as a dependency */
+				const uint64_t rmask = (1ull << lane) - 1ull;
+				(void)dep; (void)d_hi; (void)d_lo;
+#else
+				const uint64_t rmask = dep ? (2ull << d_hi) - (1ull << d_lo) : 0ull;
+#endif
+				bool fin = mlen == 0;
+				uint8_t *const mp = W + mdst;
 				const bool slow = mlen > 64 || off < mlen;
-				const uint32_t mf = (mlen != 0 && !slow && !dep) ? mlen : 0u;	/* length if the straight-line pass takes the match */
+				const uint32_t mf = (mlen != 0 && !slow) ? mlen : 0u;	/* length if the straight-line copy takes the match */
 				io_cls K;
 				K.k16 = __ballot(mf >= 16);
 				K.k32 = __ballot(mf >= 32);
@@ -418,7 +390,7 @@ __global__ __launch_bounds__(IO_THREADS, 8) void lz4_expand_inorder_kernel(
 				K.ks44 = __ballot(mf > 4 && mf < 8);
 				K.k2 = __ballot(mf != 0 && mf < 4 && (mf & 2));
 				K.k1 = __ballot(mf != 0 && mf < 4 && (mf & 1));
-				uint64_t Q = __ballot(mlen != 0 && (slow || dep));	/* the matches taken one by one afterwards */
+				const uint64_t kslow = __ballot(slow && mlen != 0);
 				io_adr A;
 				A.mp = w_lds + mdst;
 				A.fp = A.mp - off;
@@ -437,29 +409,36 @@ __global__ __launch_bounds__(IO_THREADS, 8) void lz4_expand_inorder_kernel(
 				[[maybe_unused]] const unsigned long long t_p0 = IO_NOW();
 				[[maybe_unused]] unsigned long long t_p1 = t_p0;
 
-				/* the straight-line pass: every match of at most 64 bytes that neither overlaps its source nor reaches
-				 * into the matches of its own group (about nineteen in twenty on the C2 stream) ... */
+				/* pass 1: every match whose source does not reach into a match of its own group.  Then rounds:
+				 * a lane is ready when none of the lanes it waits for is unfinished (the lowest unfinished
+				 * lane always is) */
+				uint64_t unf = __ballot(!fin);
+				uint32_t rounds = 0;
+				while (unf) {
+					const bool ready = !fin && (rmask & unf) == 0;
+					const uint64_t R = __ballot(ready);
 #ifndef IO_EXP_NO_COPY	/* timing experiment */
-				io_copy_fast(K.ks | K.k16, K, A);
+					io_copy_fast(R, K, A);
 #endif
+					if (R & kslow) {	/* longer than 64 bytes or overlapping its source: rare */
+						if (ready && slow)
+							io_copy_match(mp, off, mlen);
+					}
+					fin = fin || ready;
+					asm volatile("" ::: "memory");
 #ifdef LA_DIAG
-				t_p1 = IO_NOW();
+					if (rounds == 0) t_p1 = IO_NOW();
 #endif
-				/* ... then the others in stream order, each by the whole wave */
-				uint32_t nq = 0;
-#ifndef IO_EXP_NO_LATE	/* timing experiment (wrong output) */
-				while (Q) {
-					const uint32_t qi = (uint32_t)__builtin_ctzll(Q);
-					Q &= Q - 1;
-					const uint32_t q_md = (uint32_t)__builtin_amdgcn_readlane((int)mdst, (int)qi);
-					const uint32_t q_off = (uint32_t)__builtin_amdgcn_readlane((int)off, (int)qi);
-					const uint32_t q_ml = (uint32_t)__builtin_amdgcn_readlane((int)mlen, (int)qi);
-					io_coop_match(W + q_md, q_off, q_ml, lane);
-					nq++;
+#ifdef IO_EXP_NO_LATE	/* timing experiment: one pass only (wrong output) */
+					break;
+#endif
+					unf &= ~R;
+					if (R == 0 || ++rounds > 64u) {	/* cannot happen: the lowest unfinished lane is always ready */
+						IO_FAIL(bi);
+						break;
+					}
 				}
-#endif
-				asm volatile("" ::: "memory");
-				IO_STAMP_ADD(2, nq);
+				IO_STAMP_ADD(2, rounds);
 #ifdef LA_DIAG
 				IO_STAMP_ADD(6, t_p1 - t_p0);
 				IO_STAMP_ADD(7, IO_NOW() - t_p1);
@@ -541,10 +520,6 @@ __global__ __launch_bounds__(IO_THREADS, 8) void lz4_expand_inorder_kernel(
 				uint4 pB0, pBt;
 				uint32_t shB0, shBt;
 				IO_LOAD_P(pB0, pBt, shB0, shBt, eB);
-#ifdef LA_DIAG
-				if (g == g0 && g == 0)
-					IO_STAMP_ADD(4, IO_NOW() - t_l0);	/* loads of the iteration issued */
-#endif
 				/* this group */
 				const seq_t e = eA;
 				const uint32_t k = g * 64 + lane;
@@ -568,13 +543,6 @@ __global__ __launch_bounds__(IO_THREADS, 8) void lz4_expand_inorder_kernel(
 				if (dead)
 					ll = 0;		/* (mdst stays as computed: only consistent positions are handed on) */
 				const uint32_t G = gbase + g;
-				/* L works at most IO_RING groups ahead of M: the ring slot is free when M is done with the group IO_RING
-				 * places back -- and the literal stores of the groups M needs first are not queued behind those of groups it
-				 * needs much later (when a window is handed back every literal wave has a group ready to store) */
-				[[maybe_unused]] const unsigned long long t_r0 = IO_NOW();
-				if (G >= IO_RING && !io_wait_ge(&ctl->match_groups, G + 1 - IO_RING, ctl, 1))
-					IO_FAIL(bi);
-				IO_STAMP_ADD(11, IO_NOW() - t_r0);
 #ifdef IO_EXP_NO_LIT	/* timing experiment: no literal stores (wrong output) */
 				if (ll > 0x100000u) {
 #else
@@ -607,27 +575,35 @@ __global__ __launch_bounds__(IO_THREADS, 8) void lz4_expand_inorder_kernel(
 							lds_st16(wd + ll - 16, ld_u128(s + ls + ll - 16));
 					}
 				}
-#ifdef LA_DIAG
-				if (g == g0 && g == 0)
-					IO_STAMP_ADD(9, IO_NOW() - t_l0);	/* literals stored */
-#endif
-				/* Does the source of the match reach into the matches of its own group (it ends behind the start of the
-				 * group's first match)?  Then M takes it after the straight-line pass, in stream order. */
-				const uint32_t bm = valid ? mdst : olen;
+				/* Which matches of this group does the source of each match overlap?  The matches of the group lie in
+				 * stream order: [bm, em) of lane i ends before lane i + 1's begins.  The source [s0, send) (send: the
+				 * end of the part that exists before the copy starts) meets the lanes first .. last with
+				 * first = #{i: em_i <= s0}, last = #{i: bm_i < send} - 1: two binary searches over the lanes
+				 * (ds_bpermute), run side by side.  Both counts are below this lane's own number. */
+				const uint32_t bm = valid ? mdst : olen, em = bm + mlen;
 				const uint32_t s0 = bm - off, send = s0 + (mlen < off ? mlen : off);
-				const bool dep = mlen != 0 && send > (uint32_t)__builtin_amdgcn_readfirstlane((int)bm);
+				uint32_t cl = 0, ch = 0;
+#pragma unroll
+				for (uint32_t step = 32; step; step >>= 1) {
+					const uint32_t ve = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((cl + step - 1) << 2), (int)em);
+					const uint32_t vb = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((ch + step - 1) << 2), (int)bm);
+					if (ve <= s0) cl += step;
+					if (vb < send) ch += step;
+				}
+				const bool dep = mlen != 0 && cl < ch;	/* first = cl <= last = ch - 1 */
+				/* the ring slot is free when M is done with the group IO_RING places back */
+				[[maybe_unused]] const unsigned long long t_r0 = IO_NOW();
+				if (G >= IO_RING && !io_wait_ge(&ctl->match_groups, G + 1 - IO_RING, ctl, 1))
+					IO_FAIL(bi);
+				IO_STAMP_ADD(11, IO_NOW() - t_r0);
 				/* the records go out last, in one instruction: their tag tells M that the group's literals are in
 				 * the window too (the LDS runs a wave's instructions in order) */
 #ifdef IO_DBG_LWAIT
 				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
 				asm volatile("" ::: "memory");
-				ring[G % IO_RING][lane] = make_uint4(bm | (dep ? 1u << 29 : 0u), mlen, valid ? off : 0u, G + 1);
+				ring[G % IO_RING][lane] = make_uint4(bm | (dep ? (cl << 17) | ((ch - 1) << 23) | (1u << 29) : 0u), mlen, valid ? off : 0u, G + 1);
 				asm volatile("" ::: "memory");
-#ifdef LA_DIAG
-				if (g == g0 && g == 0)	/* the wave that writes a block's first records: window free -> records out */
-					IO_STAMP_ADD(10, IO_NOW() - t_l0);
-#endif
 				eA = eB; nA = nB;
 				eB = eC; nB = nC;
 				pA0 = pB0; pAt = pBt; shA0 = shB0; shAt = shBt;
@@ -690,13 +666,11 @@ __global__ __launch_bounds__(IO_THREADS, 8) void lz4_expand_inorder_kernel(
 					moved = true;
 				}
 				if (complete) {
-					[[maybe_unused]] const unsigned long long t_f0 = IO_NOW();
 					if (lane < head)
 						g_out[lane] = W[lane];
 					const uint32_t tail0 = head + (nunits << 4);
 					if (tail0 + lane < olen)
 						g_out[tail0 + lane] = W[tail0 + lane];
-					IO_STAMP_ADD(15, IO_NOW() - t_f0);
 					break;
 				}
 				if (moved) {
@@ -705,6 +679,7 @@ __global__ __launch_bounds__(IO_THREADS, 8) void lz4_expand_inorder_kernel(
 					IO_FAIL(bi);
 					break;
 				}
+				IO_STAMP_ADD(9, 1);
 				__builtin_amdgcn_s_sleep(4);
 			}
 			/* every LDS read of this block has returned (its data went into the stores above) */
