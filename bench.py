@@ -329,6 +329,19 @@ def zstd_object(ctx, torch):
                          "sample": "%d x %d MiB decoded, ZSTD_decompress over the 64 distinct frames, %.1f s" % (reps, 64 * kib // 1024, cpu_s)},
     }
 
+def gz_traffic(args):
+    """PMC-measured HBM bytes of the two inflate kernels per step for the C3 workload (separate rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE passes, tools/exp_traffic_gz.sh, committed as profiles/r03_traffic_gzip.json); quoted only when the file was
+    measured on the library in use and the workload is the full C3 size."""
+    tpath = os.path.join(ROOT, "profiles", "r03_traffic_gzip.json")
+    if not os.path.exists(tpath) or abs(args.gib - 16.0) > 1e-6:
+        return None
+    rec = json.load(open(tpath))
+    if rec.get("library_sha16") != kernel_source_id():
+        return None
+    return rec.get("inflate_symbols_plus_expand", {}).get("hbm_bytes_per_step")
+
+
 def main_gzip(args, as_secondary=False):
     """configs[2] shape: concatenated gzip members of 64 KiB with a BGZF-style size subfield,
     CRC32 + ISIZE verified on the device.  `--workload gzip` prints it as its own line; the default run
@@ -444,7 +457,7 @@ def main_gzip(args, as_secondary=False):
                    "compressed_bytes_per_gpu": C_bytes, "decoded_bytes_per_gpu": U_bytes},
         "bit_exact": bool(ok), "phases_ms": {k: round(float(np.mean(v)), 3) for k, v in phase_ms.items()},
         "roofline": {"bound": "hbm", "kernel": "inflate (symbols + expand)", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": gz_traffic(args),
                      "algorithmic_bytes": C_bytes + U_bytes},
         "cpu_baseline": cpu}
     ctx.close()
