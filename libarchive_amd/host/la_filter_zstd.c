@@ -13,6 +13,7 @@
 #include "la_read_private.h"
 #include "la_host.h"
 #include <errno.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -26,16 +27,26 @@ struct zstd_private {
 	int upstream_eof;
 	uint64_t skip_left;		/* bytes of a skippable frame still to pass over before anything is staged (zstd.c skips
 					 * such frames in constant memory: so does this filter) */
-	/* one decoded window */
-	la_zstd_frame *frames; uint32_t frames_cap;
-	la_zstd_result *results;
-	uint8_t *out; size_t out_cap;		/* pinned */
+	/* Two windows in flight (round 3, as the lz4 filter does): while the caller consumes the slab of window n, window
+	 * n + 1 is already gathered, indexed and queued on the device (H2D, decode, D2H into the OTHER slot's pinned slab);
+	 * only that slab copy is waited for (la_gpu_mark / la_gpu_wait_mark).  The device buffers are shared: the stream
+	 * orders window n's slab copy in front of window n + 1's decode.  What a window found (frames, results, what
+	 * follows its last frame, a refusal) stays with its slot and is reported when the slot's turn comes: bytes in
+	 * front of an error are delivered first, as the reference's loop does. */
+	struct zstd_slot {
+		la_zstd_frame *frames; uint32_t frames_cap;
+		la_zstd_result *results;
+		uint8_t *out; size_t out_cap;		/* pinned */
+		uint32_t n, next;			/* frames of the window / next to hand out */
+		int end_kind;				/* what follows the window's last frame */
+		int launched;				/* the window has been prepared (and queued when n > 0) */
+		int rc;					/* ARCHIVE_OK, or what preparing it ended with (reported at its turn) */
+		char err[200];
+	} slot[2];
+	int cur;				/* the slot being handed out */
 	void *d_src, *d_dst, *d_frames, *d_results;
 	size_t d_src_cap, d_dst_cap, d_tab_cap;
-	uint32_t n, next;			/* frames of the window / next to hand out */
-	int end_kind;				/* what follows the window's last frame */
 	int finished;				/* error or end already reported */
-	int n_windows_started;
 	int64_t total_out;
 };
 
@@ -189,25 +200,41 @@ static int zstd_fill(struct archive_read_filter *self, struct zstd_private *st, 
 	return ARCHIVE_OK;
 }
 
-/* Gather, index, decode one window.  Returns ARCHIVE_OK with st->n frames ready (possibly 0) or an error. */
-static int zstd_next_window(struct archive_read_filter *self, struct zstd_private *st)
+/* deferred failure of a window: kept with the slot, reported when the slot's turn comes */
+static int slot_fail(struct zstd_slot *sl, int rc, const char *fmt, unsigned long long v)
+{
+	sl->rc = rc;
+	snprintf(sl->err, sizeof(sl->err), fmt, v);
+	sl->n = 0;
+	sl->end_kind = LA_END_EOF;
+	return ARCHIVE_OK;
+}
+
+/* Gather, index and QUEUE one window into slot sl (H2D, decode, D2H, marker): nothing is waited for.  Returns
+ * ARCHIVE_OK with sl->launched set (sl->n frames, possibly 0; a refusal is kept in sl->rc) or an upstream error. */
+static int zstd_launch(struct archive_read_filter *self, struct zstd_private *st, struct zstd_slot *sl)
 {
 	la_zstd_index_result ir;
 	size_t want = st->batch_bytes;
+	sl->launched = 1;
+	sl->rc = ARCHIVE_OK;
+	sl->err[0] = 0;
+	sl->n = sl->next = 0;
+	sl->end_kind = LA_END_EOF;
 	for (;;) {
 		int r = zstd_fill(self, st, want);
 		if (r != ARCHIVE_OK)
 			return r;
-		if (st->frames_cap == 0) {
-			st->frames_cap = 1u << 16;
-			st->frames = malloc(sizeof(la_zstd_frame) * st->frames_cap);
-			st->results = malloc(sizeof(la_zstd_result) * st->frames_cap);
-			if (!st->frames || !st->results) {
+		if (sl->frames_cap == 0) {
+			sl->frames_cap = 1u << 16;
+			sl->frames = malloc(sizeof(la_zstd_frame) * sl->frames_cap);
+			sl->results = malloc(sizeof(la_zstd_result) * sl->frames_cap);
+			if (!sl->frames || !sl->results) {
 				archive_set_error(&self->archive->archive, ENOMEM, "Can't allocate data for zstd decompression");
 				return ARCHIVE_FATAL;
 			}
 		}
-		la_zstd_index_build(st->stage, st->stage_len, st->upstream_eof, st->out_budget, st->frames, st->frames_cap, &ir);
+		la_zstd_index_build(st->stage, st->stage_len, st->upstream_eof, st->out_budget, sl->frames, sl->frames_cap, &ir);
 		if (ir.n_frames == 0 && ir.end_kind == LA_END_NEED_MORE && !ir.window_full && !st->upstream_eof && ir.consumed > 0) {
 			/* nothing but skippable frames in front of an incomplete frame: they are done with -- drop them and gather
 			 * on in the same window (the reference skips such frames in constant memory, zstd.c:196-260; growing the
@@ -217,15 +244,12 @@ static int zstd_next_window(struct archive_read_filter *self, struct zstd_privat
 			continue;
 		}
 		if (ir.n_frames == 0 && ir.end_kind == LA_END_NEED_MORE && !ir.window_full && !st->upstream_eof) {
-			if (st->stage_len >= st->max_batch_bytes) {
+			if (st->stage_len >= st->max_batch_bytes)
 				/* ONE frame whose compressed bytes alone pass LA_GPU_MAX_BATCH_MIB: the whole frame would have to sit in
 				 * host memory and HBM; refused by name (the reference streams it) */
-				archive_set_error(&self->archive->archive, ARCHIVE_ERRNO_MISC,
+				return slot_fail(sl, ARCHIVE_FATAL,
 				    "zstd frame too large for the GPU data plane (more than %llu compressed bytes; LA_GPU_MAX_BATCH_MIB)",
 				    (unsigned long long)st->max_batch_bytes);
-				st->finished = 1;
-				return ARCHIVE_FATAL;
-			}
 			want = st->stage_len * 2 > want ? st->stage_len * 2 : want * 2;	/* one frame larger than the window: gather on */
 			if (want > st->max_batch_bytes)
 				want = st->max_batch_bytes;
@@ -233,21 +257,17 @@ static int zstd_next_window(struct archive_read_filter *self, struct zstd_privat
 		}
 		break;
 	}
-	st->n = ir.n_frames;
-	st->next = 0;
-	st->end_kind = ir.end_kind;
-	if (st->out_budget && ir.dst_bytes > st->out_budget && ir.dst_bytes > ((uint64_t)4 << 30)) {
+	sl->n = ir.n_frames;
+	sl->end_kind = ir.end_kind;
+	if (st->out_budget && ir.dst_bytes > st->out_budget && ir.dst_bytes > ((uint64_t)4 << 30))
 		/* ONE frame whose blocks may decode to more than the window's budget (the walker stops adding frames at the
 		 * budget, so this is a single frame: e.g. terabytes of one byte as RLE blocks).  The reference streams such a
 		 * frame 128 KiB at a time; this data plane decodes whole frames into HBM and refuses it by name. */
-		archive_set_error(&self->archive->archive, ARCHIVE_ERRNO_MISC,
+		return slot_fail(sl, ARCHIVE_FATAL,
 		    "zstd frame too large for the GPU data plane (its blocks may decode to %llu bytes; LA_GPU_OUT_BUDGET_MIB)",
 		    (unsigned long long)ir.dst_bytes);
-		st->finished = 1;
-		return ARCHIVE_FATAL;
-	}
-	if (st->n) {
-		const size_t tab = sizeof(la_zstd_frame) * st->n, rtab = sizeof(la_zstd_result) * st->n;
+	if (sl->n) {
+		const size_t tab = sizeof(la_zstd_frame) * sl->n, rtab = sizeof(la_zstd_result) * sl->n;
 		if (grow_dev(st, &st->d_src, &st->d_src_cap, (size_t)ir.consumed + 64) != LA_OK) return gpu_fail(self, st, "la_gpu_malloc");
 		if (grow_dev(st, &st->d_dst, &st->d_dst_cap, (size_t)ir.dst_bytes + 64) != LA_OK) return gpu_fail(self, st, "la_gpu_malloc");
 		if (tab + rtab > st->d_tab_cap) {
@@ -258,34 +278,46 @@ static int zstd_next_window(struct archive_read_filter *self, struct zstd_privat
 			st->d_tab_cap = 2 * (tab + rtab);
 		}
 		st->d_results = (uint8_t *)st->d_frames + ((tab + 15u) & ~(size_t)15u);
-		if ((size_t)ir.dst_bytes > st->out_cap) {
-			if (st->out) la_gpu_free_host(st->gpu, st->out);
-			st->out = NULL;
-			st->out_cap = 0;
+		if ((size_t)ir.dst_bytes > sl->out_cap) {
+			if (sl->out) la_gpu_free_host(st->gpu, sl->out);
+			sl->out = NULL;
+			sl->out_cap = 0;
 			void *hp = NULL;
 			const size_t nc = ((size_t)ir.dst_bytes + ((size_t)ir.dst_bytes >> 2) + 0xFFFFFu) & ~(size_t)0xFFFFFu;
 			if (la_gpu_malloc_host(st->gpu, &hp, nc) != LA_OK) return gpu_fail(self, st, "la_gpu_malloc_host");
-			st->out = hp;
-			st->out_cap = nc;
+			sl->out = hp;
+			sl->out_cap = nc;
 		}
 		if (la_gpu_memcpy_h2d(st->gpu, st->d_src, st->stage, ir.consumed) != LA_OK) return gpu_fail(self, st, "la_gpu_memcpy_h2d");
-		if (la_gpu_memcpy_h2d(st->gpu, st->d_frames, st->frames, tab) != LA_OK) return gpu_fail(self, st, "la_gpu_memcpy_h2d");
+		if (la_gpu_memcpy_h2d(st->gpu, st->d_frames, sl->frames, tab) != LA_OK) return gpu_fail(self, st, "la_gpu_memcpy_h2d");
 		la_zstd_batch bt;
 		memset(&bt, 0, sizeof(bt));
 		bt.d_src = st->d_src; bt.src_bytes = ir.consumed;
-		bt.d_frames = st->d_frames; bt.n_frames = st->n;
+		bt.d_frames = st->d_frames; bt.n_frames = sl->n;
 		bt.d_dst = st->d_dst; bt.dst_cap = ir.dst_bytes;
 		bt.d_results = st->d_results;
 		{ const char *lk = getenv("LA_ZSTD_LANE_KERNEL"); bt.options = (lk && atoi(lk) > 0) ? LA_ZSTD_OPT_LANE_KERNEL : 0u; }
 		if (la_gpu_zstd_decode(st->gpu, &bt) != LA_OK) return gpu_fail(self, st, "la_gpu_zstd_decode");
-		if (la_gpu_memcpy_d2h(st->gpu, st->results, st->d_results, rtab) != LA_OK) return gpu_fail(self, st, "la_gpu_memcpy_d2h");
-		if (ir.dst_bytes && la_gpu_memcpy_d2h(st->gpu, st->out, st->d_dst, ir.dst_bytes) != LA_OK) return gpu_fail(self, st, "la_gpu_memcpy_d2h");
-		if (la_gpu_sync(st->gpu) != LA_OK) return gpu_fail(self, st, "la_gpu_sync");
+		if (la_gpu_memcpy_d2h(st->gpu, sl->results, st->d_results, rtab) != LA_OK) return gpu_fail(self, st, "la_gpu_memcpy_d2h");
+		if (ir.dst_bytes && la_gpu_memcpy_d2h(st->gpu, sl->out, st->d_dst, ir.dst_bytes) != LA_OK) return gpu_fail(self, st, "la_gpu_memcpy_d2h");
+		/* the stage (pageable memory) and the host frame table have been read by the copies above when they return:
+		 * the marker covers the rest */
+		if (la_gpu_mark(st->gpu) != LA_OK) return gpu_fail(self, st, "la_gpu_mark");
 	}
 	/* keep what the window did not cover */
 	memmove(st->stage, st->stage + ir.consumed, st->stage_len - (size_t)ir.consumed);
 	st->stage_len -= (size_t)ir.consumed;
 	return ARCHIVE_OK;
+}
+
+/* does anything follow the window in slot sl?  (an end kind that ends the stream, or no input left) */
+static int slot_is_last(const struct zstd_private *st, const struct zstd_slot *sl)
+{
+	if (sl->rc != ARCHIVE_OK)
+		return 1;
+	if (sl->end_kind == LA_END_TRUNCATED || sl->end_kind == LA_END_ZSTD_BAD_MAGIC || sl->end_kind == LA_END_ZSTD_BAD_BLOCK)
+		return 1;
+	return sl->end_kind == LA_END_EOF && st->upstream_eof && st->stage_len == 0;
 }
 
 static ssize_t zstd_filter_read(struct archive_read_filter *self, const void **p)
@@ -295,9 +327,23 @@ static ssize_t zstd_filter_read(struct archive_read_filter *self, const void **p
 	if (st->finished)
 		return 0;
 	for (;;) {
-		while (st->next < st->n) {
-			const uint32_t i = st->next++;
-			const la_zstd_result *r = &st->results[i];
+		struct zstd_slot *sl = &st->slot[st->cur];
+		if (!sl->launched) {
+			/* the very first window: prepare it, wait for it, and put the second one in flight behind it */
+			int r = zstd_launch(self, st, sl);
+			if (r != ARCHIVE_OK)
+				return r;
+			if (sl->n && la_gpu_wait_mark(st->gpu) != LA_OK)
+				return gpu_fail(self, st, "la_gpu_wait_mark");
+			if (!slot_is_last(st, sl)) {
+				r = zstd_launch(self, st, &st->slot[st->cur ^ 1]);
+				if (r != ARCHIVE_OK)
+					return r;
+			}
+		}
+		while (sl->next < sl->n) {
+			const uint32_t i = sl->next++;
+			const la_zstd_result *r = &sl->results[i];
 			if (r->status != LA_ST_OK) {
 				archive_set_error(&self->archive->archive, ARCHIVE_ERRNO_MISC, "%s", la_status_message(r->status));
 				st->finished = 1;
@@ -308,17 +354,22 @@ static ssize_t zstd_filter_read(struct archive_read_filter *self, const void **p
 			/* frames whose output lies back to back in the slab (slots are 16-byte aligned: full slots of a
 			 * multiple of 16 bytes) go out in one read */
 			uint64_t len = r->out_len;
-			while (st->next < st->n && st->results[st->next].status == LA_ST_OK && st->results[st->next].out_len != 0 &&
-			    st->frames[st->next].dst_off == st->frames[i].dst_off + len && len < ((uint64_t)1 << 30))
-				len += st->results[st->next++].out_len;
-			*p = st->out + st->frames[i].dst_off;
+			while (sl->next < sl->n && sl->results[sl->next].status == LA_ST_OK && sl->results[sl->next].out_len != 0 &&
+			    sl->frames[sl->next].dst_off == sl->frames[i].dst_off + len && len < ((uint64_t)1 << 30))
+				len += sl->results[sl->next++].out_len;
+			*p = sl->out + sl->frames[i].dst_off;
 			st->total_out += (int64_t)len;
 			return (ssize_t)len;
 		}
-		/* the window is handed out: what came behind its last frame? */
-		if (st->n_windows_started) {
+		/* the window is handed out: what did preparing it end with, and what came behind its last frame? */
+		if (sl->rc != ARCHIVE_OK) {
+			archive_set_error(&self->archive->archive, ARCHIVE_ERRNO_MISC, "%s", sl->err);
+			st->finished = 1;
+			return sl->rc;
+		}
+		{
 			const char *m = NULL;
-			switch (st->end_kind) {
+			switch (sl->end_kind) {
 			case LA_END_TRUNCATED: m = "Truncated zstd input"; break;	/* zstd.c:213-217 */
 			case LA_END_ZSTD_BAD_MAGIC: m = "Zstd decompression failed: Unknown frame descriptor"; break;
 			case LA_END_ZSTD_BAD_BLOCK: m = "Zstd decompression failed: Corrupted block detected"; break;	/* (the device reported the frame) */
@@ -329,15 +380,29 @@ static ssize_t zstd_filter_read(struct archive_read_filter *self, const void **p
 				st->finished = 1;
 				return ARCHIVE_FATAL;
 			}
-			if (st->end_kind == LA_END_EOF) {	/* end of input on a frame boundary (zstd.c:208-211) */
+		}
+		struct zstd_slot *nx = &st->slot[st->cur ^ 1];
+		if (!nx->launched) {
+			/* nothing was put in flight behind this window: it was the last one (zstd.c:208-211: end of input on a
+			 * frame boundary), or the walker wants more input than one window gave it */
+			if (sl->end_kind == LA_END_EOF && st->upstream_eof && st->stage_len == 0) {
 				st->finished = 1;
 				return 0;
 			}
+			int r = zstd_launch(self, st, nx);
+			if (r != ARCHIVE_OK)
+				return r;
 		}
-		st->n_windows_started = 1;
-		int r = zstd_next_window(self, st);
-		if (r != ARCHIVE_OK)
-			return r;
+		/* the next window's turn: wait for its slab, then put the one after it in flight into the slot just emptied */
+		if (nx->n && la_gpu_wait_mark(st->gpu) != LA_OK)
+			return gpu_fail(self, st, "la_gpu_wait_mark");
+		st->cur ^= 1;
+		sl->launched = 0;
+		if (!slot_is_last(st, nx)) {
+			int r = zstd_launch(self, st, sl);
+			if (r != ARCHIVE_OK)
+				return r;
+		}
 	}
 }
 
@@ -350,12 +415,16 @@ static int zstd_filter_close(struct archive_read_filter *self)
 		if (st->d_src) la_gpu_free(st->gpu, st->d_src);
 		if (st->d_dst) la_gpu_free(st->gpu, st->d_dst);
 		if (st->d_frames) la_gpu_free(st->gpu, st->d_frames);
-		if (st->out) la_gpu_free_host(st->gpu, st->out);
+		(void)la_gpu_sync(st->gpu);	/* a window may still be in flight */
+		for (int i = 0; i < 2; i++)
+			if (st->slot[i].out) la_gpu_free_host(st->gpu, st->slot[i].out);
 		la_gpu_close(st->gpu);
 	}
 	free(st->stage);
-	free(st->frames);
-	free(st->results);
+	for (int i = 0; i < 2; i++) {
+		free(st->slot[i].frames);
+		free(st->slot[i].results);
+	}
 	free(st);
 	self->data = NULL;
 	return ARCHIVE_OK;
