@@ -339,6 +339,22 @@ __device__ __forceinline__ uint32_t crc_run(const uint32_t *T, uint32_t state, c
 		state = T[(state ^ *p++) & 0xff] ^ (state >> 8);
 		n--;
 	}
+	/* 64 bytes per trip, the four 16-byte loads issued together: a lane walks its OWN chunk (the lanes of a wave are a
+	 * whole chunk apart), so every 64-byte line is touched by one lane only -- loaded 16 bytes at a time the line
+	 * was gone from the caches before its next quarter was asked for (round 3, rocprofv3 FETCH_SIZE: 54 GB fetched
+	 * for the 17 GB of C3, profiles/r03_traffic_gzip.json) */
+	while (n >= 64) {
+		const uint4 *q = (const uint4 *)__builtin_assume_aligned(p, 4);
+		const uint4 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3];
+		const uint32_t w[16] = { v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w };
+#pragma unroll
+		for (int k = 0; k < 16; k++) {
+			uint32_t x = state ^ w[k];
+			state = T[768 + (x & 0xff)] ^ T[512 + ((x >> 8) & 0xff)] ^
+			    T[256 + ((x >> 16) & 0xff)] ^ T[x >> 24];
+		}
+		p += 64; n -= 64;
+	}
 	while (n >= 16) {
 		uint4 v = *(const uint4 *)__builtin_assume_aligned(p, 4);
 		uint32_t w[4] = { v.x, v.y, v.z, v.w };
