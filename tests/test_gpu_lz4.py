@@ -262,3 +262,75 @@ def test_blocks_of_runs_long_and_medium(gpu_ctx):
     ref, res = O.lz4_stream_decode(img, len(plain) + 16)
     assert res.rc == 0 and ref.tobytes() == plain
     assert gpu_decode(gpu_ctx, img) == (plain, 0, "")
+
+
+def _craft_block(rnd, nseq, lit_lo, lit_hi, ml_lo, ml_hi, near=False, period=None):
+    """A hand-built LZ4 block of exactly `nseq` sequences (the last one literals only) and what it decodes to: literal
+    runs of lit_lo..lit_hi bytes, matches of ml_lo..ml_hi bytes at random offsets (`near`: within the last 64 bytes, so
+    that sources reach into the 64 sequences in front of them; `period`: overlapping matches of that offset)."""
+    out = bytearray()
+    blk = bytearray()
+
+    def lens(v):
+        b = bytearray()
+        while v >= 255:
+            b.append(255)
+            v -= 255
+        b.append(v)
+        return b
+
+    for k in range(nseq):
+        last = k == nseq - 1
+        ll = rnd.randint(max(lit_lo, 5 if last else (1 if len(out) == 0 else lit_lo)), max(lit_hi, 12 if last else lit_hi))
+        lit = bytes(rnd.randrange(256) for _ in range(ll))
+        if last:
+            blk.append(min(ll, 15) << 4)
+            if ll >= 15:
+                blk += lens(ll - 15)
+            blk += lit
+            out += lit
+            break
+        out += lit
+        ml = rnd.randint(ml_lo, ml_hi)
+        if period:
+            off = min(period, len(out))
+        elif near:
+            off = rnd.randint(1, min(64, len(out)))
+        else:
+            off = rnd.randint(1, len(out))
+        blk.append((min(ll, 15) << 4) | min(ml - 4, 15))
+        if ll >= 15:
+            blk += lens(ll - 15)
+        blk += lit + off.to_bytes(2, "little")
+        if ml - 4 >= 15:
+            blk += lens(ml - 4 - 15)
+        for _ in range(ml):
+            out.append(out[-off])
+        if len(out) > 60000:
+            nseq = k + 2      # close the block with the next (literal-only) sequence
+    return bytes(blk), bytes(out)
+
+
+def test_group_boundaries_of_the_in_order_kernel(gpu_ctx):
+    """Blocks whose sequence counts sit on and around the in-order kernel's group size (64 sequences per group, six
+    literal waves, eight-group record ring): 1, 2, 63, 64, 65, 127, 128, 129, 383, 384, 385, 512, 513 sequences, with
+    far, near (in-group dependencies: chains of up to 64 rounds) and overlapping sources, literal runs up to 40 bytes
+    (past the 32 the literal waves prefetch) and matches up to 300 bytes (past the 64 of the straight-line copy)."""
+    rnd = random.Random(20261005)
+    blocks, plain = [], bytearray()
+    for n in (1, 2, 63, 64, 65, 127, 128, 129, 383, 384, 385, 512, 513):
+        for kw in (dict(lit_lo=0, lit_hi=6, ml_lo=4, ml_hi=40), dict(lit_lo=0, lit_hi=3, ml_lo=4, ml_hi=12, near=True),
+                   dict(lit_lo=0, lit_hi=40, ml_lo=4, ml_hi=300), dict(lit_lo=1, lit_hi=4, ml_lo=4, ml_hi=70, period=rnd.randint(1, 20))):
+            payload, dec = _craft_block(rnd, n, **kw)
+            if len(dec) > 65536:
+                continue
+            blocks.append((dec, S.lz4_block(payload, bsum=True)))
+            plain += dec
+    img = b""
+    for i in range(0, len(blocks), 5):
+        f, _ = S.lz4_frame(blocks[i:i + 5], flg=0x74)
+        img += f
+    ref, res = O.lz4_stream_decode(img, len(plain) + 16)
+    assert res.rc == 0 and ref.tobytes() == bytes(plain)
+    out, rc, msg = gpu_decode(gpu_ctx, img)
+    assert (rc, msg) == (0, "") and out == bytes(plain)
