@@ -48,6 +48,17 @@
 #ifndef IL_LIT_BURST
 #define IL_LIT_BURST 3	/* (3 x 15 bits fit the one refill of a burst) */
 #endif
+/* Diagnostic build only (make diag): wave-level counters, added by the first active lane of whatever
+ * subset of the wave runs the region.  No output value depends on them. */
+#ifdef LA_DIAG
+__device__ unsigned long long *la_diag_il;
+#define IL_FIRST_LANE() ((int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == __builtin_ffsll((long long)__ballot(1)) - 1)
+#define IL_CNT(slot, v) do { if (la_diag_il && IL_FIRST_LANE()) atomicAdd(&la_diag_il[slot], (unsigned long long)(v)); } while (0)
+#define IL_NOW() __builtin_readcyclecounter()
+#else
+#define IL_CNT(slot, v) do { } while (0)
+#define IL_NOW() 0ull
+#endif
 #define IL_SCRATCH_PER_LANE 1024u	/* bytes of global scratch per member: lens[320] + sorted symbols u16[320] + pad */
 
 /* ---- per-lane LDS tables, transposed: element e of lane t at [e][t] ---- */
@@ -144,18 +155,23 @@ __device__ __forceinline__ void lb_seek(lane_bits &B, uint32_t ip)
 /* top the buffer up to >= 56 bits.  The bytes come from `cur`; the load that replaces
  * what was used is issued now and only needed at the NEXT refill, so its latency is
  * hidden behind the symbols in between.  Bytes past iend may come along (they exist in
- * the image or are zero) and are never COUNTED as available: see lb_avail(). */
+ * the image or are zero) and are never COUNTED as available: see lb_avail().
+ * NO BRANCH on purpose (round 3): with `if (take)` around the reload the old and the new `nxt`
+ * meet in a phi, the compiler copies the freshly loaded register pair at the end of the branch
+ * and puts `s_waitcnt vmcnt(0)` in front of the copy -- every refill then waited for its OWN
+ * prefetch, a full global round trip, two to three times per outer iteration (seen in the ISA;
+ * 52 % of the wave cycles were SQ_WAIT_ANY).  With take == 0 the same address is simply asked
+ * for again. */
 __device__ __forceinline__ void lb_refill(lane_bits &B)
 {
 	B.hold |= B.cur << B.bits;
 	const uint32_t take = (63u - B.bits) >> 3;
 	B.bits += take * 8;
-	if (take) {
-		B.ip += take;
-		const uint64_t nx = lb_fix(B.nxt, B.nxt_drop);	/* requested one refill ago */
-		B.cur = (B.cur >> (8 * take)) | (nx << (64 - 8 * take));
-		B.nxt = lb_load8_raw(B, B.ip + 8, &B.nxt_drop);
-	}
+	B.ip += take;
+	const uint64_t nx = lb_fix(B.nxt, B.nxt_drop);	/* requested one refill ago */
+	const uint64_t moved = (B.cur >> (8 * take)) | (nx << ((64 - 8 * take) & 63));
+	B.cur = take ? moved : B.cur;
+	B.nxt = lb_load8_raw(B, B.ip + 8, &B.nxt_drop);
 }
 /* bits of REAL input still unread (may be negative when the buffer ran past iend) */
 __device__ __forceinline__ int32_t lb_avail(const lane_bits &B)
@@ -171,7 +187,31 @@ struct lane_code {
 	uint32_t maxlen;
 	uint32_t first_p, index_p;	/* canonical-walk state after the lengths the fast table covers */
 	packed16 nlow;		/* literal/length code only: symbols below 256 per length */
+	uint32_t y0, y1, y2, y3, y4, y5, y6, y7;	/* distance / code-length code only: the (at most 32) symbols in
+				 * canonical order, one byte each, IN REGISTERS (named scalars: an array
+				 * would be indexed through scratch memory): a long distance code then
+				 * costs a few selects instead of a trip to global scratch that the whole
+				 * wave waits for */
 };
+__device__ __forceinline__ void lc_sym_set(lane_code &C, uint32_t pos, uint32_t sy)
+{
+	const uint32_t sh = 8u * (pos & 3u), w = pos >> 2, keep = ~(0xFFu << sh), put = sy << sh;
+#define LC_SET(i, f) C.f = w == i ? ((C.f & keep) | put) : C.f
+	LC_SET(0, y0); LC_SET(1, y1); LC_SET(2, y2); LC_SET(3, y3);
+	LC_SET(4, y4); LC_SET(5, y5); LC_SET(6, y6); LC_SET(7, y7);
+#undef LC_SET
+}
+/* (masks, not selects: a chain of selects over loads from the struct is folded by the compiler into ONE load
+ * through a selected address, which pins the whole struct in scratch memory) */
+__device__ __forceinline__ uint32_t lc_sym_get(const lane_code &C, uint32_t pos)
+{
+	const uint32_t w = pos >> 2;
+#define LC_M(i) (0u - (uint32_t)(w == i))
+	const uint32_t v = (C.y0 & LC_M(0)) | (C.y1 & LC_M(1)) | (C.y2 & LC_M(2)) | (C.y3 & LC_M(3)) |
+	    (C.y4 & LC_M(4)) | (C.y5 & LC_M(5)) | (C.y6 & LC_M(6)) | (C.y7 & LC_M(7));
+#undef LC_M
+	return (v >> (8u * (pos & 3u))) & 0xFFu;
+}
 
 /*
  * Build one table from lens[0..n) (global scratch, this lane's): counts, sorted symbol
@@ -179,11 +219,13 @@ struct lane_code {
  * Returns 0 complete, >0 incomplete, <0 over-subscribed.
  */
 template <int FAST_BITS, bool LL>
-__device__ int il_build(const uint8_t *lens, int n, lane_code &C, uint16_t *sorted,
+__device__ __forceinline__ int il_build(const uint8_t *lens, int n, lane_code &C, uint16_t *sorted,
     il_lds &T, int tid)
 {
 	p16_zero(C.count);
 	p16_zero(C.nlow);
+	if (!LL)
+		C.y0 = C.y1 = C.y2 = C.y3 = C.y4 = C.y5 = C.y6 = C.y7 = 0;
 	for (int i = 0; i < n; i++)
 		p16_add(C.count, lens[i], 1);
 	int left = 1, maxlen = 0;
@@ -227,8 +269,10 @@ __device__ int il_build(const uint8_t *lens, int n, lane_code &C, uint16_t *sort
 #endif
 			if (sy < 256)
 				p16_add(C.nlow, l, 1);
-		} else {
+		} else if (LL) {
 			sorted[pos] = (uint16_t)sy;
+		} else {
+			lc_sym_set(C, pos & 31u, (uint32_t)sy);
 		}
 		const uint32_t cw = p16_get(next_code, l);
 		p16_add(next_code, l, 1);
@@ -262,12 +306,14 @@ __device__ __forceinline__ int il_decode(lane_bits &B, const lane_code &C, const
 	 * tried in straight-line code on the next 15 bits (every lane of the wave pays for this
 	 * path whenever one lane takes it, so it has no loop and no dynamic counter picks). */
 	const uint32_t rev = __builtin_bitreverse32(lb_peek(B, 15)) >> 17;	/* first bit read = bit 14 */
+	IL_CNT(LL ? 4 : 8, 1);
 	int first = (int)C.first_p, index = (int)C.index_p;
 	int hit_len = 0, hit_idx = 0, hit_hi = 0;
 #pragma unroll
 	for (int k = FAST_BITS + 1; k <= 15; k++) {
 		if (__ballot(hit_len == 0 && (uint32_t)k <= C.maxlen) == 0)
 			break;	/* (wave-uniform) every lane here has its code, or no longer ones exist */
+		IL_CNT(LL ? 5 : 9, 1);
 		const int cn = (int)((C.count.w[k >> 2] >> (16 * (k & 3))) & 0xFFFFu);
 		const int codev = (int)(rev >> (15 - k));
 		const bool hit = hit_len == 0 && (uint32_t)k <= C.maxlen && codev - cn < first;
@@ -285,6 +331,8 @@ __device__ __forceinline__ int il_decode(lane_bits &B, const lane_code &C, const
 		if (LL)
 			return (int)T.sl[hit_idx][tid] | hit_hi;
 #endif
+		if (!LL)
+			return (int)lc_sym_get(C, (uint32_t)hit_idx & 31u);
 		return sorted[hit_idx];
 	}
 	{
@@ -359,6 +407,9 @@ __global__ __launch_bounds__(IL_THREADS) void inflate_lanes_kernel(const uint8_t
 	/* EMIT state: literal and sequence counts, current literal run */
 	uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0;	/* literal accumulator */
 	uint64_t pend = 0;
+	uint32_t pl0 = 0, pl1 = 0, pl2 = 0, pl3 = 0, pl_at = 0, pt_at = 0;	/* stores waiting for a flush point */
+	uint64_t pt_a = 0, pt_b = 0;
+	bool pl_on = false, pt_on = false;
 	uint32_t nl = 0, ns = 0, run_src = 0, run_dst = 0;
 	bool overflow = false;
 	uint8_t *const litb = EMIT ? E.lit + (uint64_t)mi * 65536u : nullptr;
@@ -376,17 +427,31 @@ __global__ __launch_bounds__(IL_THREADS) void inflate_lanes_kernel(const uint8_t
 		q2 = __builtin_amdgcn_alignbit(q3, q2, 8);                                        \
 		q3 = __builtin_amdgcn_alignbit((uint32_t)(byte_), q3, 8);                         \
 		nl++;                                                                             \
-		if ((nl & 15u) == 0)                                                              \
-			*(uint4 *)(litb + nl - 16) = make_uint4(q0, q1, q2, q3);                  \
+		if ((nl & 15u) == 0) {                                                            \
+			pl0 = q0; pl1 = q1; pl2 = q2; pl3 = q3; pl_at = nl - 16; pl_on = true;        \
+		}                                                                                 \
+	} while (0)
+/* Stores do not leave where they arise: a finished group of sixteen literals and a finished pair of
+ * table entries wait in registers for the next FLUSH POINT, right behind a bit-buffer refill.  The
+ * refill waits for the prefetch of the refill before it, and the memory counter it waits on counts
+ * stores too (in order): a store issued just in front of that wait would be waited for in full,
+ * one issued just behind it has a whole literal burst to complete in. */
+#define IL_FLUSH()                                                                                \
+	do {                                                                                      \
+		if (pl_on) { *(uint4 *)(litb + pl_at) = make_uint4(pl0, pl1, pl2, pl3); pl_on = false; } \
+		if (pt_on) {                                                                      \
+			*(uint4 *)(tabp + pt_at) = make_uint4((uint32_t)pt_a, (uint32_t)(pt_a >> 32), (uint32_t)pt_b, (uint32_t)(pt_b >> 32)); \
+			pt_on = false;                                                            \
+		}                                                                                 \
 	} while (0)
 #define IL_PUT_SEQ(off_)                                                                          \
 	do {                                                                                      \
 		if (ns >= LA_INFLATE_MAXSEQ) { overflow = true; goto done; }                     \
 		const uint64_t e_ = (uint64_t)(run_src | ((nl - run_src) << 16)) |                 \
 		    ((uint64_t)(run_dst | ((uint32_t)(off_) << 16)) << 32);                       \
-		if (ns & 1u)                                                                      \
-			*(uint4 *)(tabp + ns - 1) = make_uint4((uint32_t)pend, (uint32_t)(pend >> 32), (uint32_t)e_, (uint32_t)(e_ >> 32)); \
-		else                                                                              \
+		if (ns & 1u) {                                                                    \
+			pt_a = pend; pt_b = e_; pt_at = ns - 1; pt_on = true;                         \
+		} else                                                                            \
 			pend = e_;                                                                \
 		ns++;                                                                             \
 	} while (0)
@@ -413,8 +478,11 @@ __global__ __launch_bounds__(IL_THREADS) void inflate_lanes_kernel(const uint8_t
 	CL.maxlen = CD.maxlen = 0;
 	p16_zero(CL.count); p16_zero(CD.count);
 
+	[[maybe_unused]] const unsigned long long il_t_start = IL_NOW();
 	for (;;) {
+		[[maybe_unused]] const unsigned long long il_t_hdr = IL_NOW();
 		lb_refill(B);
+		if (EMIT) IL_FLUSH();
 		const uint32_t last = lb_peek(B, 1);
 		const uint32_t type = (lb_peek(B, 3) >> 1);
 		lb_drop(B, 3);
@@ -437,6 +505,7 @@ __global__ __launch_bounds__(IL_THREADS) void inflate_lanes_kernel(const uint8_t
 				for (uint32_t j = 0; j < take; j++) {
 					const uint32_t by = B.s[B.ip + j];
 					IL_PUT_LIT(by);
+					IL_FLUSH();
 				}
 			} else {
 				for (uint32_t j = 0; j < take; j++)
@@ -522,8 +591,11 @@ __global__ __launch_bounds__(IL_THREADS) void inflate_lanes_kernel(const uint8_t
 				e = il_build<DT_BITS, false>(lens + nlen, ndist, CD, sorted_d, T, tid);
 				if (e < 0 || (e > 0 && CD.maxlen > 1)) { status = LA_ST_GZ_DATA; goto done; }
 			}
+			IL_CNT(2, IL_NOW() - il_t_hdr);
+			IL_CNT(3, 1);
 			/* ---- symbols ---- */
 			for (;;) {
+				IL_CNT(6, 1);
 				/* 48 bits cover one literal/length code, its extra bits, a distance code and
 				 * its extra bits (15 + 5 + 15 + 13): reload only when fewer are left, i.e.
 				 * every few symbols instead of every symbol */
@@ -542,6 +614,7 @@ __global__ __launch_bounds__(IL_THREADS) void inflate_lanes_kernel(const uint8_t
 #pragma unroll	/* IL_LIT_ROUNDS bursts back to back before the match path: it is paid per outer iteration */
 				for (int rnd = 0; rnd < IL_LIT_ROUNDS; rnd++) {
 					lb_refill(B);
+					if (EMIT) IL_FLUSH();
 #pragma unroll	/* (no loop around the burst: a loop head makes the compiler wait for the prefetch there) */
 					for (int burst = 0; burst < IL_LIT_BURST; burst++) {
 						sym = il_decode<LL_BITS, true>(B, CL, sorted_ll, T, tid, &used);
@@ -565,8 +638,8 @@ __global__ __launch_bounds__(IL_THREADS) void inflate_lanes_kernel(const uint8_t
 				if (sym == 256)
 					break;
 				/* (after a literal run the buffer may hold fewer than the 33 bits the rest needs) */
-				if (B.bits < 40)
-					lb_refill(B);
+				lb_refill(B);	/* (unconditional: a branch around it makes the refill wait for its own prefetch, see lb_refill) */
+				IL_CNT(7, 1);
 				sym -= 257;
 				if (sym >= 29) { status = LA_ST_GZ_DATA; goto done; }
 				uint32_t xb, bs;
@@ -622,6 +695,9 @@ __global__ __launch_bounds__(IL_THREADS) void inflate_lanes_kernel(const uint8_t
 			break;
 	}
 done:
+	if ((tid & 63) == 0) { IL_CNT(0, IL_NOW() - il_t_start); IL_CNT(1, 1); }
+	IL_CNT(10, ns); IL_CNT(11, nl);
+	if (EMIT) IL_FLUSH();
 	{
 		/* bytes consumed = up to and including the byte that holds the last bit used */
 		uint32_t consumed = B.ip - (B.bits >> 3);
@@ -687,7 +763,16 @@ done:
 	}
 #undef IL_PUT_LIT
 #undef IL_PUT_SEQ
+#undef IL_FLUSH
 }
+
+#ifdef LA_DIAG
+extern "C" int la_diag_set_il_counters(void *d_buf)
+{
+	unsigned long long *p = (unsigned long long *)d_buf;
+	return (int)hipMemcpyToSymbol(HIP_SYMBOL(la_diag_il), &p, sizeof(p));
+}
+#endif
 
 uint64_t la_inflate_lanes_scratch_bytes(uint32_t n)
 {
