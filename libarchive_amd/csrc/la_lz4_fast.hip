@@ -355,6 +355,66 @@ __global__ __launch_bounds__(FAST_THREADS, FAST_MIN_WAVES) void lz4_expand_fast_
 	 * First every step's dependency range [q, qend] (branch-free binary searches over
 	 * the output positions, interleaved across steps), then the steps in order. */
 	uint32_t qcur[MAXSTEPS];	/* search cursor, then (first dependency | count << 16) */
+#ifndef FAST_BSEARCH
+	/* The sequence under a source position comes from a MAP, not from a binary search over the output
+	 * positions (twelve dependent LDS reads per sequence: a third of the kernel's LDS cycles, PMC + count
+	 * in DESIGN.md 5c): for every 32-byte chunk of the output the sequence that holds the chunk's first
+	 * byte, then a short walk forward (a chunk holds at most eight sequence starts; half a one on the C2
+	 * stream).  The map lives where phase L kept its chunk index: that is dead behind the barrier above. */
+	uint16_t *const cmap = chunk_first;
+#pragma unroll
+	for (uint32_t r = 0; r < MAXSTEPS; r++) {
+		if (r * FAST_THREADS >= ns)
+			break;
+		const uint32_t k = fast_seq_index(r, wave, lane);
+		if (k < ns) {
+			const uint32_t d = SEQ_DST(ent[r]);
+			uint32_t nxt = dstpos[k + 1];
+			if (nxt < d)
+				nxt = 65536u;	/* (positions are 16-bit: an end at 65536 reads 0; a lone sequence that
+						 * fills the window leaves the map unset, and nobody asks) */
+			if (k == 0)
+				for (uint32_t c = 0; (c << 5) < d; c++)
+					cmap[c] = 0;	/* (later segments: positions in front of the segment) */
+			for (uint32_t c = (d + 31) >> 5; (c << 5) < nxt; c++)
+				cmap[c] = (uint16_t)k;
+		}
+	}
+	__syncthreads();
+#pragma unroll
+	for (uint32_t r = 0; r < MAXSTEPS; r++) {
+		qcur[r] = 0;
+		if (r * FAST_THREADS >= ns)
+			continue;
+		const uint32_t k = fast_seq_index(r, wave, lane);
+		const uint32_t s0 = SEQ_DST(ent[r]) + SEQ_LIT_LEN(ent[r]) - SEQ_OFF(ent[r]);
+		if (k > 0 && k < ns) {
+			const uint32_t q0 = cmap[(s0 < 65535u ? s0 : 65535u) >> 5];
+			qcur[r] = q0 < k - 1 ? q0 : k - 1;	/* largest idx < k with dstpos[idx] <= s0, from below */
+		}
+	}
+	{
+		uint32_t act = 0;	/* wave-uniform: slots in which some lane is still walking */
+#pragma unroll
+		for (uint32_t r = 0; r < MAXSTEPS; r++)
+			if (r * FAST_THREADS < ns)
+				act |= 1u << r;
+		while (act) {
+#pragma unroll
+			for (uint32_t r = 0; r < MAXSTEPS; r++) {
+				if (!((act >> r) & 1u))
+					continue;
+				const uint32_t k = fast_seq_index(r, wave, lane);
+				const uint32_t s0 = SEQ_DST(ent[r]) + SEQ_LIT_LEN(ent[r]) - SEQ_OFF(ent[r]);
+				const bool adv = k < ns && qcur[r] + 1 < k && dstpos[qcur[r] + 1] <= s0;
+				if (adv)
+					qcur[r]++;
+				if (__ballot(adv) == 0)
+					act &= ~(1u << r);
+			}
+		}
+	}
+#else
 #pragma unroll
 	for (uint32_t r = 0; r < MAXSTEPS; r++)
 		qcur[r] = 0;
@@ -371,6 +431,7 @@ __global__ __launch_bounds__(FAST_THREADS, FAST_MIN_WAVES) void lz4_expand_fast_
 				qcur[r] = cand;
 		}
 	}
+#endif
 	/* Literals are all in the window already (phase L), so a match only has to wait for
 	 * earlier MATCHES under its source range.  The last sequence the range touches is
 	 * often touched in its literal part only (a sequence is literals first, match second):
