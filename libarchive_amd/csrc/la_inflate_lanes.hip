@@ -8,12 +8,15 @@
  * the parallel axis is "members", exactly as the LZ4 parse kernel walks one token
  * chain per lane.  Each lane owns
  *   - a 64-bit bit buffer refilled with unaligned 8-byte loads of its member,
- *   - its Huffman fast tables in LDS, TRANSPOSED ([entry][lane]) so that 64
- *     lanes looking up 64 different codes never meet in a bank:
- *         256 x u16 literal/length table (8-bit index) + 64 x u16 distance table
- *         (6-bit index) = 640 B per lane, 256 lanes = the CU's whole 160 KiB;
- *     longer codes fall back to a canonical walk over per-lane arrays in a
- *     global scratch area (rare),
+ *   - its Huffman code in REGISTERS and LDS (round 3, IL_CANON): the literal/length code is resolved by a
+ *     canonical walk -- the next 15 bits, left-justified, against one limit per code length (the limits grow
+ *     with the length), branch-free, four operations per length; limit, index bias and the "symbols from 256
+ *     up start here" mark of every length live in registers.  LDS holds only what needs an index:
+ *         288 x u8  the literal/length symbols in canonical order (low byte), TRANSPOSED ([entry][lane]) so
+ *                   that 64 lanes looking up 64 different symbols do not queue on one lane's row,
+ *         32 x u8   distance fast table (5-bit index; longer distance codes: a walk over counts, the at most
+ *                   32 symbols sit in registers), also used for the code-length code of a block header,
+ *     = 320 B per lane, 80 KiB per 256-lane workgroup: TWO workgroups per CU, two waves per SIMD,
  *   - its output slot in the slab: literals are single byte stores, matches are
  *     8-byte "wild" copies (a lane reads back its own earlier stores, which the
  *     hardware keeps coherent per thread; bytes past a match are overwritten by
@@ -21,23 +24,34 @@
  * The wave-per-member kernel of la_inflate.hip stays the path for small batches
  * and for members whose slot is too small for wild copies.
  *
- * Tried and not kept: more waves per SIMD.  The tables of 256 lanes fill the CU's LDS, so one
- * wave runs per SIMD.  With the long-code symbol list moved to global scratch (IL_SL_GLOBAL=1,
- * 320 B per lane, two workgroups per CU), also with 6-bit / 5-bit fast tables (four per CU) or
- * 128-lane workgroups, the entropy decode of 16 GiB went from 94.6 ms to 114 / 144 / 138 ms: the
- * one wave already keeps its SIMD's issue slots busy (every lane's path is executed by the whole
- * wave), a second wave only adds its instructions to the same queue and the longer code walks.
+ * How it got here (entropy decode of the 16 GiB C3 stream, ms; profiles/README.md round 3):
+ *   94.1  round 2: 7-bit literal/length fast table + 6-bit distance table + symbol list, 608 B per lane, ONE
+ *         workgroup per CU.  Two workgroups per CU were tried then with smaller tables or the symbol list in
+ *         global memory and were SLOWER (114-144): the measurement was dominated by something else --
+ *   81.2  the ISA showed every bit-buffer refill waiting for its OWN prefetch (s_waitcnt vmcnt(0) in front of a
+ *         register copy at the end of `if (take) {...}`: a phi of the old and the new load) and every long
+ *         distance code fetching its symbol from global scratch; SQ_WAIT_ANY was 52 % of the wave cycles.
+ *         Branch-free refill, stores collected at flush points right behind the refill, distance symbols in
+ *         registers: 38 % waiting, the rest is instruction issue -- one wave per SIMD issues a dependent
+ *         instruction only every ~8 cycles.
+ *   46.7  so a second wave per SIMD pays once the tables fit twice: on the C3 members nearly every literal code
+ *         is longer than the 7-bit table anyway (random literals: 8-9 bits), the table bought nothing there, and
+ *         the canonical walk costs the same whatever the code length.  (IL_CANON=0 keeps the table version.)
  */
 #include "la_dev.h"
 
 #ifndef IL_THREADS
 #define IL_THREADS 256
 #endif
+#ifndef IL_CANON
+#define IL_CANON 1	/* 1: no literal/length fast table; every literal/length code resolves by the canonical walk over
+			 * per-length limits kept in registers, 320 B of LDS per lane, TWO workgroups per CU */
+#endif
 #ifndef LL_BITS
 #define LL_BITS 7
 #endif
 #ifndef DT_BITS
-#define DT_BITS 6
+#define DT_BITS (IL_CANON ? 5 : 6)
 #endif
 #ifndef IL_SL_GLOBAL
 #define IL_SL_GLOBAL 0	/* 1: the literal/length symbol list for long codes lives in global scratch, not LDS */
@@ -72,7 +86,9 @@ __device__ unsigned long long *la_diag_il;
  *   dt  fast table of the distance code (and, while a block header is read, of the
  *       code-length code), DT_BITS wide, entry = symbol << 3 | length */
 struct il_lds {
+#if !IL_CANON
 	uint16_t ll[1 << LL_BITS][IL_THREADS];
+#endif
 #if !IL_SL_GLOBAL
 	uint8_t sl[288][IL_THREADS];
 #endif
@@ -187,6 +203,12 @@ struct lane_code {
 	uint32_t maxlen;
 	uint32_t first_p, index_p;	/* canonical-walk state after the lengths the fast table covers */
 	packed16 nlow;		/* literal/length code only: symbols below 256 per length */
+#if IL_CANON
+	/* literal/length code, canonical walk: per length k, lim[k] = (left-justified 15-bit end of the codes of
+	 * length k) | (index of the length's first symbol - its first code) << 16, hib[k] = index from which the
+	 * length's symbols are 256 and up; bit k of `has`: the code has words of length k */
+	uint32_t lim[16], hib[16], has;
+#endif
 	uint32_t y0, y1, y2, y3, y4, y5, y6, y7;	/* distance / code-length code only: the (at most 32) symbols in
 				 * canonical order, one byte each, IN REGISTERS (named scalars: an array
 				 * would be indexed through scratch memory): a long distance code then
@@ -253,8 +275,27 @@ __device__ __forceinline__ int il_build(const uint8_t *lens, int n, lane_code &C
 		C.first_p = fi;
 		C.index_p = ix;
 	}
+#if IL_CANON
+	if (LL) {
+		uint32_t cd = 0, ix = 0;
+		C.has = 0;
+		C.lim[0] = C.hib[0] = 0;
+#pragma unroll
+		for (int l = 1; l < 16; l++) {
+			const uint32_t c = p16_get(C.count, l);
+			cd = (cd + (l > 1 ? p16_get(C.count, l - 1) : 0u)) << 1;	/* first code of length l */
+			C.lim[l] = (((cd + c) << (15 - l)) & 0xFFFFu) | ((ix - cd) << 16);
+			C.hib[l] = ix;	/* (+ the literals of this length, below) */
+			C.has |= (c ? 1u : 0u) << l;
+			ix += c;
+		}
+	} else
+#endif
 	for (int i = 0; i < (1 << FAST_BITS); i++) {
-		if (LL) T.ll[i][tid] = 0; else T.dt[i][tid] = 0;
+#if !IL_CANON
+		if (LL) T.ll[i][tid] = 0; else
+#endif
+		T.dt[i][tid] = 0;
 	}
 	if (left < 0)
 		return -1;
@@ -276,14 +317,24 @@ __device__ __forceinline__ int il_build(const uint8_t *lens, int n, lane_code &C
 		}
 		const uint32_t cw = p16_get(next_code, l);
 		p16_add(next_code, l, 1);
-		if (l <= (uint32_t)FAST_BITS) {
+		if (l <= (uint32_t)FAST_BITS && !(IL_CANON && LL)) {
 			const uint32_t r = __builtin_bitreverse32(cw) >> (32 - l);
 			for (uint32_t idx = r; idx < (1u << FAST_BITS); idx += (1u << l)) {
+#if !IL_CANON
 				if (LL) T.ll[idx][tid] = (uint16_t)((sy << 4) | l);
-				else T.dt[idx][tid] = (uint8_t)((sy << 3) | l);
+				else
+#endif
+				T.dt[idx][tid] = (uint8_t)((sy << 3) | l);
 			}
 		}
 	}
+#if IL_CANON
+	if (LL) {
+#pragma unroll
+		for (int l = 1; l < 16; l++)
+			C.hib[l] += p16_get(C.nlow, l);
+	}
+#endif
 	return left;
 }
 
@@ -291,10 +342,52 @@ __device__ __forceinline__ int il_build(const uint8_t *lens, int n, lane_code &C
  * The caller checks availability of the consumed bits afterwards. */
 template <int FAST_BITS, bool LL>
 __device__ __forceinline__ int il_decode(lane_bits &B, const lane_code &C, const uint16_t *sorted,
-    const il_lds &T, int tid, uint32_t *used)
+    const il_lds &T, int tid, uint32_t *used, uint32_t whas = 0)
 {
+#if IL_CANON
+	if (LL) {
+		/* the code's 15-bit left-justified value against the per-length limits (they grow with the
+		 * length): the first limit above it is the code's length.  Lengths nobody in the wave has words
+		 * of cost a test and a jump; a length somebody has costs seven operations for everybody. */
+		const uint32_t rev = __builtin_bitreverse32(lb_peek(B, 15)) >> 17;	/* first bit read = bit 14 */
+		IL_CNT(4, 1);
+		/* Branch-free, longest length first: every length whose limit lies above the code overwrites the
+		 * choice, so the SHORTEST such length stands at the end (the limits grow with the length; lengths
+		 * the code has no words of repeat their neighbour's limit and change nothing).  Four operations per
+		 * length; the rare lengths (1-3 and 13-15 bits) sit behind one wave-uniform test each (`whas`:
+		 * the lengths some lane of the wave has words of, set up once per block). */
+		uint32_t hit_len = 0, bias = 0, hb = 0;
+#define IL_TRY(k)                                                                     \
+		do {                                                                  \
+			const uint32_t a_ = C.lim[k];                                 \
+			const bool under_ = rev < (a_ & 0xFFFFu);                     \
+			hit_len = under_ ? (uint32_t)(k) : hit_len;                   \
+			bias = under_ ? (uint32_t)((int32_t)a_ >> 16) : bias;         \
+			hb = under_ ? C.hib[k] : hb;                                  \
+		} while (0)
+		if (whas & 0xE000u) { IL_TRY(15); IL_TRY(14); IL_TRY(13); }
+		IL_TRY(12); IL_TRY(11); IL_TRY(10); IL_TRY(9); IL_TRY(8); IL_TRY(7); IL_TRY(6); IL_TRY(5); IL_TRY(4);
+		if (whas & 0x000Eu) { IL_TRY(3); IL_TRY(2); IL_TRY(1); }
+#undef IL_TRY
+		IL_CNT(5, 9);
+		const uint32_t hit_idx = (rev >> (15u - hit_len)) + bias;	/* (hit_len 0: unused) */
+		const uint32_t hit_hi = hit_idx >= hb ? 256u : 0u;
+		if (hit_len) {
+			lb_drop(B, hit_len);
+			*used = hit_len;
+			return (int)((uint32_t)T.sl[hit_idx][tid] | hit_hi);
+		}
+		const uint32_t ml = C.maxlen ? C.maxlen : 1;
+		lb_drop(B, ml);
+		*used = ml;
+		return -2;
+	}
+	const uint32_t e = (uint32_t)T.dt[lb_peek(B, FAST_BITS)][tid];
+	const uint32_t l = e & 7u;
+#else
 	const uint32_t e = LL ? (uint32_t)T.ll[lb_peek(B, FAST_BITS)][tid] : (uint32_t)T.dt[lb_peek(B, FAST_BITS)][tid];
 	const uint32_t l = LL ? (e & 15u) : (e & 7u);
+#endif
 	if (l) {
 		lb_drop(B, l);
 		*used = l;
@@ -591,6 +684,14 @@ __global__ __launch_bounds__(IL_THREADS) void inflate_lanes_kernel(const uint8_t
 				e = il_build<DT_BITS, false>(lens + nlen, ndist, CD, sorted_d, T, tid);
 				if (e < 0 || (e > 0 && CD.maxlen > 1)) { status = LA_ST_GZ_DATA; goto done; }
 			}
+			uint32_t whas = 0;
+#if IL_CANON
+			/* the lanes that run the symbol loop together keep their codes for all of it: which code
+			 * lengths exist among them is one wave-uniform word for the whole loop */
+#pragma unroll
+			for (int k = 1; k <= 15; k++)
+				whas |= __ballot((CL.has >> k) & 1u) ? 1u << k : 0u;
+#endif
 			IL_CNT(2, IL_NOW() - il_t_hdr);
 			IL_CNT(3, 1);
 			/* ---- symbols ---- */
@@ -617,7 +718,7 @@ __global__ __launch_bounds__(IL_THREADS) void inflate_lanes_kernel(const uint8_t
 					if (EMIT) IL_FLUSH();
 #pragma unroll	/* (no loop around the burst: a loop head makes the compiler wait for the prefetch there) */
 					for (int burst = 0; burst < IL_LIT_BURST; burst++) {
-						sym = il_decode<LL_BITS, true>(B, CL, sorted_ll, T, tid, &used);
+						sym = il_decode<LL_BITS, true>(B, CL, sorted_ll, T, tid, &used, whas);
 						IL_CHECK_TRUNC();
 						if (sym < 0) { status = LA_ST_GZ_DATA; goto done; }
 						if (sym >= 256)

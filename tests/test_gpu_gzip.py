@@ -216,3 +216,172 @@ def test_many_members_batch(gpu_ctx):
     bodies = [deflate(d, 6) + trailer(d) for d in datas]
     res, sm = gpu_inflate(gpu_ctx, bodies, [len(d) for d in datas])
     assert all(r[0] == ST_OK and r[1] == d for r, d in zip(res, datas))
+
+
+# ---------------------------------------------------------------- hand-built dynamic blocks
+
+class _Bits:
+    """LSB-first bit writer (RFC 1951 3.1.1); Huffman codes go in MSB-first."""
+    def __init__(self):
+        self.acc, self.n, self.out = 0, 0, bytearray()
+
+    def put(self, v, nbits):
+        self.acc |= (v & ((1 << nbits) - 1)) << self.n
+        self.n += nbits
+        while self.n >= 8:
+            self.out.append(self.acc & 255)
+            self.acc >>= 8
+            self.n -= 8
+
+    def code(self, c, nbits):
+        self.put(int(format(c, "0%db" % nbits)[::-1], 2), nbits)
+
+    def done(self):
+        if self.n:
+            self.out.append(self.acc & 255)
+        return bytes(self.out)
+
+
+def _canon(lens):
+    """symbol -> (code, length), canonical assignment of RFC 1951 3.2.2"""
+    bl = [0] * 16
+    for l in lens:
+        bl[l] += 1 if l else 0
+    nxt, c = [0] * 16, 0
+    for b in range(1, 16):
+        c = (c + bl[b - 1]) << 1
+        nxt[b] = c
+    out = {}
+    for sy, l in enumerate(lens):
+        if l:
+            out[sy] = (nxt[l], l)
+            nxt[l] += 1
+    return out
+
+
+_LEN_BASE = [3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258]
+_LEN_XB = [0] * 8 + [1] * 4 + [2] * 4 + [3] * 4 + [4] * 4 + [5] * 4 + [0]
+_DIST_BASE = [1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577]
+_DIST_XB = [0, 0, 0, 0] + [i // 2 for i in range(2, 28)]
+
+
+def _dynamic_block(ll_lens, d_lens, ops, final=True):
+    """One dynamic-Huffman block with the GIVEN code lengths (286 / 30 entries).  The lengths are sent one by one
+    (no repeat codes) through a flat code-length code: sixteen 4-bit words for the lengths 0..15.
+    ops: ints (literal bytes) or (length symbol index, extra value, distance symbol, extra value)."""
+    w = _Bits()
+    w.put(1 if final else 0, 1)
+    w.put(2, 2)
+    nlen, ndist = 286, 30
+    w.put(nlen - 257, 5)
+    w.put(ndist - 1, 5)
+    w.put(19 - 4, 4)
+    order = [16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15]
+    cl_lens = [4 if s < 16 else 0 for s in range(19)]		# sixteen 4-bit codes: a complete code
+    for s in order:
+        w.put(cl_lens[s], 3)
+    clc = _canon(cl_lens)
+    for l in list(ll_lens) + list(d_lens):
+        w.code(*clc[l])
+    ll, dd = _canon(ll_lens), _canon(d_lens)
+    for op in ops:
+        if isinstance(op, int):
+            w.code(*ll[op])
+        else:
+            ls, lx, ds, dx = op
+            w.code(*ll[257 + ls])
+            w.put(lx, _LEN_XB[ls])
+            w.code(*dd[ds])
+            w.put(dx, _DIST_XB[ds])
+    w.code(*ll[256])
+    return w
+
+
+def test_hand_built_codes_of_every_length(gpu_ctx):
+    """The canonical walk of the entropy decoder (per-length limits in registers, no fast table) against codes
+    zlib's deflate never emits: literal/length and distance codes that use EVERY length from 1 to 15 bits, with
+    symbols of 256 and up spread over the lengths (the `hib` split inside a length), a block that holds the
+    end-of-block code alone (an incomplete code of one 1-bit word: legal), a lone 1-bit distance code and its
+    unassigned sibling (data error), an over-subscribed code (data error).  Expected bytes from zlib's inflate."""
+    rnd = random.Random(99)
+    bodies, datas, expect_err = [], [], []
+    for trial in range(12):
+        # sixteen literal/length symbols with lengths 1..14,15,15 (Kraft sum exactly 1), assignment shuffled per trial
+        pool_lit = rnd.sample(range(256), 9)
+        pool_len = rnd.sample(range(29), 6)			# length symbols 257 + i
+        syms = pool_lit + [256] + [257 + i for i in pool_len]
+        rnd.shuffle(syms)
+        ll_lens = [0] * 286
+        for sy, l in zip(syms, list(range(1, 15)) + [15, 15]):
+            ll_lens[sy] = l
+        dsyms = rnd.sample(range(30), 16)
+        d_lens = [0] * 30
+        for sy, l in zip(dsyms, list(range(1, 15)) + [15, 15]):
+            d_lens[sy] = l
+        ops, plain = [], bytearray()
+        for _ in range(rnd.randint(50, 400)):
+            if plain and rnd.random() < 0.4:
+                ls = rnd.choice(pool_len)
+                lx = rnd.getrandbits(_LEN_XB[ls]) if _LEN_XB[ls] else 0
+                length = _LEN_BASE[ls] + lx
+                cands = [d for d in dsyms if _DIST_BASE[d] <= len(plain)]
+                if not cands:
+                    continue
+                ds = rnd.choice(cands)
+                dx = rnd.getrandbits(_DIST_XB[ds]) if _DIST_XB[ds] else 0
+                dist = _DIST_BASE[ds] + dx
+                if dist > len(plain):
+                    dx, dist = 0, _DIST_BASE[ds]
+                if len(plain) + length > 60000:
+                    continue
+                ops.append((ls, lx, ds, dx))
+                for _i in range(length):
+                    plain.append(plain[-dist])
+            else:
+                b = rnd.choice(pool_lit)
+                ops.append(b)
+                plain.append(b)
+        body = _dynamic_block(ll_lens, d_lens, ops).done()
+        assert zlib.decompressobj(-15).decompress(body) == bytes(plain)
+        bodies.append(body + trailer(bytes(plain))); datas.append(bytes(plain)); expect_err.append(False)
+    # a block of the end-of-block code alone, then a stored block with the payload
+    only_eob = [0] * 286
+    only_eob[256] = 1
+    one_d = [0] * 30
+    one_d[0] = 1
+    w = _dynamic_block(only_eob, one_d, [], final=False)
+    w.put(1, 1); w.put(0, 2)
+    w.put(0, (8 - w.n) % 8)
+    pay = b"stored after an empty dynamic block"
+    w.put(len(pay), 16); w.put(len(pay) ^ 0xFFFF, 16)
+    body = w.done() + pay
+    assert zlib.decompressobj(-15).decompress(body) == pay
+    bodies.append(body + trailer(pay)); datas.append(pay); expect_err.append(False)
+    # one 1-bit distance code: its word works, the unassigned sibling is a data error
+    ll2 = [0] * 286
+    ll2[65], ll2[256], ll2[257] = 2, 2, 1
+    for use_bad in (False, True):
+        body = _dynamic_block(ll2, one_d, [65, (0, 0, 0, 0)]).done()
+        if use_bad:
+            # the same block with the OTHER distance bit: take back the end-of-block code (2 bits) behind the
+            # literal, then length code, the unassigned distance word '1', end of block
+            w = _dynamic_block(ll2, one_d, [65])
+            total = len(w.out) * 8 + w.n - 2
+            bits = int.from_bytes(bytes(w.out) + bytes([w.acc]), "little") & ((1 << total) - 1)
+            w2 = _Bits(); w2.put(bits, total)
+            w2.code(*_canon(ll2)[257]); w2.put(1, 1)
+            w2.code(*_canon(ll2)[256])
+            body = w2.done()
+        bodies.append(body + trailer(b"AAAA")); datas.append(b"AAAA"); expect_err.append(use_bad)
+    # over-subscribed literal/length code: three 1-bit words
+    ll3 = [0] * 286
+    ll3[65], ll3[66], ll3[256] = 1, 1, 1
+    bodies.append(_dynamic_block(ll3, one_d, []).done() + trailer(b"")); datas.append(b""); expect_err.append(True)
+    res, sm = gpu_inflate(gpu_ctx, bodies, [max(len(d), 8) + 8 for d in datas])
+    for (st, out, cons, crc), d, b, bad in zip(res, datas, bodies, expect_err):
+        rc, ocons, oout = O.inflate_raw(b, len(d) + 64)
+        if bad:
+            assert rc != 0 and st == ST_DATA and out == oout
+        else:
+            assert rc == 0 and oout == d
+            assert (st, out, cons, crc) == (ST_OK, d, ocons, zlib.crc32(d) & 0xFFFFFFFF)
