@@ -44,6 +44,7 @@ struct gzip_private {
 	la_gpu_ctx *gpu;
 	uint8_t *stage;
 	size_t stage_cap, stage_len, batch_bytes;
+	size_t target_bytes;	/* the window ramps up to this size (16, 32, 64 MiB ...: la_filter_lz4.c, init) */
 	int upstream_eof;
 	void *d_src, *d_dst, *d_tabs;
 	size_t d_src_cap, d_dst_cap, d_tabs_cap;
@@ -168,7 +169,8 @@ static int gzip_bidder_init(struct archive_read_filter *self)
 		return ARCHIVE_FATAL;
 	}
 	const char *dev = getenv("LA_GPU_DEVICE"), *bm = getenv("LA_GPU_BATCH_MIB"), *sv = getenv("LA_GZIP_STRICT");
-	st->batch_bytes = (size_t)(bm && atoi(bm) > 0 ? atoi(bm) : 256) << 20;
+	st->target_bytes = (size_t)(bm && atoi(bm) > 0 ? atoi(bm) : 64) << 20;
+	st->batch_bytes = st->target_bytes < ((size_t)16 << 20) ? st->target_bytes : (size_t)16 << 20;
 	st->strict = sv && atoi(sv) != 0;
 	st->slot_limit = 0x80000000u;
 	{
@@ -561,6 +563,8 @@ static int gz_prepare(struct archive_read_filter *self, struct gzip_private *st)
 		return rc;
 	}
 	st->inflight = 1;
+	if (st->batch_bytes < st->target_bytes)
+		st->batch_bytes = st->batch_bytes * 2 < st->target_bytes ? st->batch_bytes * 2 : st->target_bytes;
 	if (st->trace)
 		fprintf(stderr, "la_gzip: window %zu bytes, %u members queued: gather %.1f ms, index + launch %.1f ms\n",
 		    st->stage_len, st->idx.n, t1 - t0, gz_now() - t1);

@@ -20,6 +20,7 @@
 struct zstd_private {
 	la_gpu_ctx *gpu;
 	size_t batch_bytes;		/* compressed bytes gathered per window */
+	size_t target_bytes;		/* the window ramps up to this size (16, 32, 64 MiB ...: la_filter_lz4.c, init) */
 	uint64_t out_budget;		/* decoded bytes asked for per window */
 	size_t max_batch_bytes;		/* how far the stage may grow for ONE frame larger than a window */
 	/* stage: compressed bytes not decoded yet */
@@ -103,7 +104,8 @@ static int zstd_reader_init(struct archive_read_filter *self)
 	}
 	const char *dev = getenv("LA_GPU_DEVICE");
 	const char *bm = getenv("LA_GPU_BATCH_MIB");
-	st->batch_bytes = (size_t)(bm && atoi(bm) > 0 ? atoi(bm) : 256) << 20;
+	st->target_bytes = (size_t)(bm && atoi(bm) > 0 ? atoi(bm) : 64) << 20;
+	st->batch_bytes = st->target_bytes < ((size_t)16 << 20) ? st->target_bytes : (size_t)16 << 20;
 	const char *ob = getenv("LA_GPU_OUT_BUDGET_MIB");
 	st->out_budget = (uint64_t)(ob && atoi(ob) > 0 ? atoi(ob) : 4096) << 20;
 	const char *bmx = getenv("LA_GPU_MAX_BATCH_MIB");
@@ -259,6 +261,8 @@ static int zstd_launch(struct archive_read_filter *self, struct zstd_private *st
 	}
 	sl->n = ir.n_frames;
 	sl->end_kind = ir.end_kind;
+	if (st->batch_bytes < st->target_bytes)
+		st->batch_bytes = st->batch_bytes * 2 < st->target_bytes ? st->batch_bytes * 2 : st->target_bytes;
 	if (st->out_budget && ir.dst_bytes > st->out_budget && ir.dst_bytes > ((uint64_t)4 << 30))
 		/* ONE frame whose blocks may decode to more than the window's budget (the walker stops adding frames at the
 		 * budget, so this is a single frame: e.g. terabytes of one byte as RLE blocks).  The reference streams such a
