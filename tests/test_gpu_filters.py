@@ -486,3 +486,16 @@ def test_gzip_window_bounded_by_decoded_bytes(gpu_ctx, monkeypatch):
         assert la_api.as_reference_tuple(r) == ref, variant
         if variant == 0:
             assert len(ref[0]) == plain_len and len(r.block_sizes) >= 4     # several bounded windows
+
+
+def test_lz4_stream_across_the_window_ramp(gpu_ctx, monkeypatch):
+    """Default windows: the first one holds 16 MiB of the stream, the next 32, then 64 (la_filter_lz4.c, init).  A
+    C2-shaped stream of 150 MiB decoded (about 66 MiB compressed) passes all three sizes; frames straddle every window
+    edge (a frame is 1 MiB decoded, about 450 KiB compressed: no window size is a multiple of it)."""
+    monkeypatch.delenv("LA_GPU_BATCH_MIB", raising=False)
+    img, plain = S.synth_lz4_stream(0x52414D50, 0, 150, nthreads=8)
+    assert img.size > (48 << 20)
+    out = la_api.cat(img.tobytes(), read_size=1 << 20)
+    got, rc, msg = la_api.as_reference_tuple(out)
+    assert (rc, msg) == (0, "") and len(got) == plain.size
+    assert got == plain.tobytes()
