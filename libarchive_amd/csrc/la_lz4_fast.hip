@@ -499,7 +499,11 @@ __global__ __launch_bounds__(FAST_THREADS, FAST_MIN_WAVES) void lz4_expand_fast_
 		const uint32_t mlen = active ? (next - mdst) & 0xFFFFu : 0;
 		const uint32_t s0 = mdst - off;
 		uint32_t q = qp & 0xFFFFu;
+#ifdef FAST_EXP_NODEP
+		const uint32_t qstop = q;	/* what-if (wrong output): nobody waits for anybody */
+#else
 		const uint32_t qstop = q + (qp >> 16);	/* exclusive; q == qstop: nothing to wait for */
+#endif
 		uint32_t spins = 0;
 		bool fin = mlen == 0;
 		if (active && fin)
@@ -533,6 +537,7 @@ __global__ __launch_bounds__(FAST_THREADS, FAST_MIN_WAVES) void lz4_expand_fast_
 					asm volatile("" ::: "memory");
 					uint8_t *mp = W + mdst;
 					const uint8_t *fp = W + s0;
+#ifndef FAST_EXP_NOCOPY	/* (what-if, wrong output: the flag protocol alone) */
 					if (off >= mlen) {
 						/* Source and destination do not overlap.  ONE LDS round trip per 64
 						 * bytes: every load is issued before anything is stored, and the
@@ -601,6 +606,9 @@ __global__ __launch_bounds__(FAST_THREADS, FAST_MIN_WAVES) void lz4_expand_fast_
 						for (uint32_t i = 0; i < mlen; i++)
 							{ uint8_t bq = mp[(int)i - (int)off]; asm volatile("" ::: "memory"); mp[i] = bq; asm volatile("" ::: "memory"); }
 					}
+#else
+					(void)mp; (void)fp;
+#endif
 					asm volatile("" ::: "memory");
 					atomicOr(&donebits[k >> 5], 1u << (k & 31));
 					fin = true;

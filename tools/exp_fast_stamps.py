@@ -29,6 +29,12 @@ print("blocks %d  mean cycles per workgroup %.0f  (median %.0f)" % (nb, tot.mean
 for i, nme in enumerate(names):
     d = st[:, i + 1] - st[:, i]
     print("  %-18s mean %8.0f  median %8.0f  share %.1f%%" % (nme, d.mean(), np.median(d), 100 * d.sum() / tot.sum()))
+if os.environ.get("LA_DIAG_L"):
+    # diag library built with -DLA_DIAG_L: stamps 6 / 7 are timestamps inside the first phase
+    a = st[:, 6] - st[:, 0]; b = st[:, 7] - st[:, 6]; c = st[:, 1] - st[:, 7]
+    print("  inside prepass+literals: entries loaded, chunk index and positions published, barrier %.0f; chunk's table entries back %.0f; literal stores %.0f"
+          % (a.mean(), b.mean(), c.mean()))
+    sys.exit(0)
 raw = stamps.cpu().numpy().reshape(nb, 8).astype(np.uint64)
 M40 = np.uint64((1 << 40) - 1)
 scan = (raw[:, 6] & M40).astype(np.float64); rounds = (raw[:, 6] >> np.uint64(40)).astype(np.float64)
