@@ -12,13 +12,31 @@ import streams as S
 
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 opts = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "0,2,8,10").split(",")]
-img, _ = S.synth_lz4_stream(0x4C413335, 0, frames, nthreads=16, want_plain=False)
+if os.environ.get("LA_EXP_TEXT"):
+    # text-like blocks through liblz4: thousands of short sequences per 64 KiB block (the segmented launch's work)
+    import random
+    rnd = random.Random(5)
+    nw = int(os.environ["LA_EXP_TEXT"])
+    words = [bytes(rnd.choice(b"abcdefghijklmnopqrstuvwxyz") for _ in range(rnd.randint(2, 9))) + b" " for _ in range(nw)]
+    blocks = []
+    for _ in range(64):
+        d = bytearray()
+        while len(d) < 65536:
+            d += rnd.choice(words)
+        d = bytes(d[:65536])
+        blocks.append((d, S.lz4_block(S.lz4_compress_block(d), bsum=True)))
+    one = b"".join(S.lz4_frame(blocks[i:i + 16], flg=0x74)[0] for i in range(0, 64, 16))
+    img = np.frombuffer(one * (frames // 4), dtype=np.uint8).copy()
+else:
+    img, _ = S.synth_lz4_stream(0x4C413335, 0, frames, nthreads=16, want_plain=False)
 idx = la.lz4_index(img)
 ctx = la.GpuContext(0); ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 d_src = torch.from_numpy(img).cuda()
 plan = Lz4DevicePlan(ctx, d_src, idx)
 C, U = img.size, int(idx.max_out)
 print("frames %d, blocks %d, C %.1f MB, U %.1f MB" % (frames, plan.n_blocks, C / 1e6, U / 1e6))
+if os.environ.get("LA_EXP_TEXT"):
+    ns = plan.nseq_host() if hasattr(plan, "nseq_host") else None
 for o in opts:
     for _ in range(2):
         plan.run(o)
