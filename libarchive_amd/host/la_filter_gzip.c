@@ -50,6 +50,17 @@ struct gzip_private {
 	size_t d_src_cap, d_dst_cap, d_tabs_cap;
 	uint8_t *slab;		/* [carry | this batch's bytes] */
 	size_t slab_cap;
+	/* The second slab: while the caller holds `slab`, the NEXT window's decoded bytes are already on their way into this
+	 * one (queued behind the decode by gz_prepare, at the offset the carry will take).  When the window turns out as
+	 * its index promised -- every member exactly as long as its ISIZE said, nothing refused -- the bytes are in place
+	 * when the next read() looks, the carry is put in front and the two slabs change roles; otherwise the copy is done
+	 * again the ordinary way.  (The lz4 and zstd filters have two whole slots; here one slab more is what was missing.) */
+	uint8_t *slab2;
+	size_t slab2_cap;
+	int no_ahead;		/* LA_GZ_NO_COPY_AHEAD=1 (measurements: the single-slab behaviour of round 2) */
+	int ahead_ok;		/* a copy into slab2 is queued ... */
+	size_t ahead_rem;	/* ... behind this many carry bytes ... */
+	size_t ahead_len;	/* ... this long */
 	size_t carry_len;	/* decoded but not yet delivered (< 64 KiB) */
 	size_t last_ret;	/* bytes handed out by the previous read() */
 	la_gz_result *h_res;
@@ -181,6 +192,7 @@ static int gzip_bidder_init(struct archive_read_filter *self)
 	const char *ob = getenv("LA_GPU_OUT_BUDGET_MIB");
 	st->out_budget = (uint64_t)(ob && atoi(ob) > 0 ? atoi(ob) : 4096) << 20;
 	st->trace = getenv("LA_GPU_TRACE") != NULL && atoi(getenv("LA_GPU_TRACE")) != 0;
+	st->no_ahead = getenv("LA_GZ_NO_COPY_AHEAD") != NULL && atoi(getenv("LA_GZ_NO_COPY_AHEAD")) != 0;
 	int rc = la_gpu_open(dev ? atoi(dev) : 0, &st->gpu);
 	if (rc != LA_OK) {
 		archive_set_error(&self->archive->archive, ARCHIVE_ERRNO_MISC,
@@ -446,11 +458,20 @@ static int gzip_run_batch(struct archive_read_filter *self, struct gzip_private 
 
 	/* ---- bring the bytes of members [0, take) behind the carry ---- */
 	uint64_t new_bytes = (total - st->total_out) + last_out;
-	if (gz_grow_pinned(st, &st->slab, &st->slab_cap, st->carry_len + (size_t)new_bytes + 16, st->carry_len) < 0)
+	const int ahead = st->ahead_ok && take && contiguous && last_out == 0 && st->carry_len == st->ahead_rem &&
+	    new_bytes <= st->ahead_len;
+	st->ahead_ok = 0;
+	if (ahead) {
+		/* they came over while the caller was busy (the sync above covered the copy): carry in front, change slabs */
+		if (st->carry_len)
+			memcpy(st->slab2, st->slab, st->carry_len);
+		uint8_t *tp = st->slab; st->slab = st->slab2; st->slab2 = tp;
+		size_t tc = st->slab_cap; st->slab_cap = st->slab2_cap; st->slab2_cap = tc;
+	} else if (gz_grow_pinned(st, &st->slab, &st->slab_cap, st->carry_len + (size_t)new_bytes + 16, st->carry_len) < 0)
 		return gz_gpu_fail(self, st, "pinned slab allocation");
 	uint8_t *dstp = st->slab + st->carry_len;
 	const double b2 = st->trace ? gz_now() : 0;
-	if (take) {
+	if (take && !ahead) {
 		if (contiguous && last_out == 0) {
 			if (la_gpu_memcpy_d2h(st->gpu, dstp, st->d_dst, (size_t)new_bytes) != LA_OK)
 				return gz_gpu_fail(self, st, "device to host copy");
@@ -467,8 +488,8 @@ static int gzip_run_batch(struct archive_read_filter *self, struct gzip_private 
 			return gz_gpu_fail(self, st, "device to host copy");
 	}
 	if (st->trace)
-		fprintf(stderr, "la_gzip:   h2d+decode %.1f ms, walk+grow %.1f ms, d2h %.1f ms (%llu bytes, contiguous %d)\n",
-		    b1 - b0, b2 - b1, gz_now() - b2, (unsigned long long)new_bytes, contiguous);
+		fprintf(stderr, "la_gzip:   h2d+decode %.1f ms, walk+grow %.1f ms, d2h %.1f ms (%llu bytes, contiguous %d, copied ahead %d)\n",
+		    b1 - b0, b2 - b1, gz_now() - b2, (unsigned long long)new_bytes, contiguous, ahead);
 	st->total_out = total + last_out;
 	st->carry_len += (size_t)new_bytes;
 
@@ -563,6 +584,21 @@ static int gz_prepare(struct archive_read_filter *self, struct gzip_private *st)
 		return rc;
 	}
 	st->inflight = 1;
+	/* decoded bytes of this window towards the OTHER slab, behind the place of what will be left of the carry: only for a
+	 * window whose boundaries and sizes are the index's own (no guessed boundary, no retry hints) and of ordinary size */
+	st->ahead_ok = 0;
+	/* (not before the window ramp has reached its target: a second pinned slab costs about half a millisecond per MiB, and one
+	 * that has to grow three times costs a short stream more than the copies it hides) */
+	if (!st->no_ahead && st->batch_bytes >= st->target_bytes && !st->idx.speculative && st->hint_skip == 0 && st->hint_cap == 0 && st->idx.max_out != 0 &&
+	    st->idx.max_out <= ((uint64_t)1 << 30) && st->carry_len >= st->last_ret) {
+		const size_t rem = st->carry_len - st->last_ret;
+		if (gz_grow_pinned(st, &st->slab2, &st->slab2_cap, rem + (size_t)st->idx.max_out + 16, 0) == 0 &&
+		    la_gpu_memcpy_d2h(st->gpu, st->slab2 + rem, st->d_dst, (size_t)st->idx.max_out) == LA_OK) {
+			st->ahead_ok = 1;
+			st->ahead_rem = rem;
+			st->ahead_len = (size_t)st->idx.max_out;
+		}
+	}
 	if (st->batch_bytes < st->target_bytes)
 		st->batch_bytes = st->batch_bytes * 2 < st->target_bytes ? st->batch_bytes * 2 : st->target_bytes;
 	if (st->trace)
@@ -651,6 +687,7 @@ static int gzip_filter_close(struct archive_read_filter *self)
 			la_gz_index_free(&st->idx);
 		if (st->stage) la_gpu_free_host(st->gpu, st->stage);
 		if (st->slab) la_gpu_free_host(st->gpu, st->slab);
+		if (st->slab2) la_gpu_free_host(st->gpu, st->slab2);
 		if (st->d_src) la_gpu_free(st->gpu, st->d_src);
 		if (st->d_dst) la_gpu_free(st->gpu, st->d_dst);
 		if (st->d_tabs) la_gpu_free(st->gpu, st->d_tabs);

@@ -499,3 +499,33 @@ def test_lz4_stream_across_the_window_ramp(gpu_ctx, monkeypatch):
     got, rc, msg = la_api.as_reference_tuple(out)
     assert (rc, msg) == (0, "") and len(got) == plain.size
     assert got == plain.tobytes()
+
+
+def test_gzip_indexed_members_copy_ahead_across_many_windows(gpu_ctx, monkeypatch):
+    """The gzip filter's second slab (round 3): for a window of indexed members the decoded bytes are copied towards the
+    OTHER slab behind the decode, at the offset the carry will take, and the slabs change roles when the window came out
+    as indexed.  Members of every size (so that the held-back partial 64 KiB block -- the carry -- has every length),
+    several 1 MiB windows, small and large reads; then the same stream with a lying size subfield in the middle (the
+    copy-ahead is dropped for the retry) and with a damaged member (bytes before it, then the reference's error)."""
+    monkeypatch.setenv("LA_GPU_BATCH_MIB", "1")
+    rnd = random.Random(4242)
+    words = [rnd.randbytes(rnd.randint(2, 12)) for _ in range(500)]
+    datas = []
+    for i in range(420):
+        n = rnd.choice([1, 7, 100, 4000, 20000, 65280, 65280, 65280, rnd.randint(1, 65280)])
+        datas.append(b"".join(rnd.choice(words) for _ in range(n // 4 + 1))[:n])
+    plain = b"".join(datas)
+    good = b"".join(_bgzf_member(d, level=rnd.choice([1, 6])) for d in datas)
+    assert len(good) > (4 << 20)
+    ref, _ = oracle_tuple(good, "gzip")
+    assert ref == (plain, 0, "")
+    for rs in (None, 4096, 1000003):
+        assert la_api.as_reference_tuple(la_api.cat(good, read_size=rs)) == ref, rs
+    lying = b"".join(_bgzf_member(d, bsize_delta=(-9 if i == 200 else 31 if i == 333 else 0)) for i, d in enumerate(datas))
+    ref, _ = oracle_tuple(lying, "gzip")
+    assert ref == (plain, 0, "")
+    assert la_api.as_reference_tuple(la_api.cat(lying, read_size=65536)) == ref
+    bad = bytearray(good)
+    bad[len(good) * 2 // 3] ^= 0x81
+    ref, _ = oracle_tuple(bytes(bad), "gzip")
+    assert la_api.as_reference_tuple(la_api.cat(bytes(bad))) == ref

@@ -50,6 +50,7 @@ from test_gpu_filters import (  # noqa: E402,F401
     test_gzip_mutated_streams,
     test_gzip_members_with_unusual_xfl_os_bytes,
     test_gzip_bgzf_indexed_members_through_the_filter,
+    test_gzip_indexed_members_copy_ahead_across_many_windows,
     test_gzip_single_member_across_windows,
     test_lz4_window_bounded_by_decoded_bytes,
     test_gzip_bid_only_indexed_switch,
