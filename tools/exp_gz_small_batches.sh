@@ -1,7 +1,7 @@
 #!/bin/bash
 # gzip decode time per batch for small batches: lane-per-member two-phase (default from 512 members), forced wave-per-member (2),
 # forced two-phase (8).  diagnostic; usage: exp_gz_small_batches.sh > out
-for mib in 16 32 64 128 256 1024; do
+for mib in 64 128 192 256 384 512 1024; do
   for opt in 0 2 8; do
     gib=$(python -c "print($mib/1024)")
     echo -n "decoded $mib MiB ($((mib*16)) members) options $opt: "
