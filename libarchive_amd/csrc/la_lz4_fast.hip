@@ -467,6 +467,9 @@ __global__ __launch_bounds__(FAST_THREADS, FAST_MIN_WAVES) void lz4_expand_fast_
 		}
 		qcur[r] = (qcur[r] & 0xFFFFu) | (cnt << 16);
 	}
+#ifdef LA_DIAG_M
+	STAMP(6);	/* chunk map, walks and dependency ranges done */
+#endif
 #pragma unroll
 	for (uint32_t h = 0; h < MAXSTEPS; h += 4) {	/* four entries in flight at a time: registers */
 		if (h * FAST_THREADS >= ns)
@@ -481,6 +484,9 @@ __global__ __launch_bounds__(FAST_THREADS, FAST_MIN_WAVES) void lz4_expand_fast_
 				qcur[h + r] -= 1u << 16;	/* source ends inside the literals of the last sequence: its match is not needed */
 	}
 
+#ifdef LA_DIAG_M
+	STAMP(7);	/* the last touched sequence's entry looked up (global memory) */
+#endif
 #pragma unroll 1
 	for (uint32_t r = 0; r < MAXSTEPS; r++) {
 		if (r * FAST_THREADS >= ns)
@@ -510,7 +516,7 @@ __global__ __launch_bounds__(FAST_THREADS, FAST_MIN_WAVES) void lz4_expand_fast_
 			atomicOr(&donebits[k >> 5], 1u << (k & 31));
 
 		for (;;) {
-#if defined(LA_DIAG) && !defined(LA_DIAG_L)
+#if defined(LA_DIAG) && !defined(LA_DIAG_L) && !defined(LA_DIAG_M)
 			if (lane == 0 && la_diag_stamps) atomicAdd(&la_diag_stamps[(size_t)blockIdx.x * 8 + 6], 1ull);
 			const unsigned long long t_it0 = __builtin_readcyclecounter();
 #endif
@@ -614,7 +620,7 @@ __global__ __launch_bounds__(FAST_THREADS, FAST_MIN_WAVES) void lz4_expand_fast_
 					fin = true;
 				}
 			}
-#if defined(LA_DIAG) && !defined(LA_DIAG_L)
+#if defined(LA_DIAG) && !defined(LA_DIAG_L) && !defined(LA_DIAG_M)
 			if (lane == 0 && la_diag_stamps) atomicAdd(&la_diag_stamps[(size_t)blockIdx.x * 8 + 7], __builtin_readcyclecounter() - t_it0);
 #endif
 			if (__ballot(!fin) == 0)

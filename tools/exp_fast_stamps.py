@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import libarchive_amd._native as N
-N.GPU_LIB_PATH = os.path.join(ROOT, "libarchive_amd", "csrc", "libla_gpu_diag.so")
+N.GPU_LIB_PATH = os.environ.get("LA_DIAG_LIB") or os.path.join(ROOT, "libarchive_amd", "csrc", "libla_gpu_diag.so")
 import libarchive_amd as la
 from libarchive_amd.lz4 import Lz4DevicePlan
 import streams as S
@@ -33,6 +33,12 @@ if os.environ.get("LA_DIAG_L"):
     # diag library built with -DLA_DIAG_L: stamps 6 / 7 are timestamps inside the first phase
     a = st[:, 6] - st[:, 0]; b = st[:, 7] - st[:, 6]; c = st[:, 1] - st[:, 7]
     print("  inside prepass+literals: entries loaded, chunk index and positions published, barrier %.0f; chunk's table entries back %.0f; literal stores %.0f"
+          % (a.mean(), b.mean(), c.mean()))
+    sys.exit(0)
+if os.environ.get("LA_DIAG_M"):
+    # diag library built with -DLA_DIAG_M: stamps 6 / 7 are timestamps inside the match phase
+    a = st[:, 6] - st[:, 2]; b = st[:, 7] - st[:, 6]; c = st[:, 3] - st[:, 7]
+    print("  inside matches: chunk map + walks + dependency ranges %.0f; last-sequence entries from global memory %.0f; the eight slots %.0f"
           % (a.mean(), b.mean(), c.mean()))
     sys.exit(0)
 raw = stamps.cpu().numpy().reshape(nb, 8).astype(np.uint64)
